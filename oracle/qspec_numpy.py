@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE — torch-free numpy restatement of QSPEC v1.
+
+Parity status: *parity unpinned by the reference* (``/root/reference`` has no source for this path;
+only ``/root/reference/CODE_OF_CONDUCT.md:1-80`` exists).  Pinned instead against
+``tests/golden/*.npz`` (produced by ``oracle/torch_ref.py`` around ``torch._int_mm``).
+
+Tensors are numpy arrays.  Half types are carried as ``uint16`` bit patterns with a dtype tag:
+``"bf16"``, ``"fp16"``, ``"f32"`` (codes 0/1/2 — the same codes ``include/pq_hip.h`` uses).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DT_BF16, DT_FP16, DT_F32 = 0, 1, 2
+_NAMES = {"bf16": DT_BF16, "fp16": DT_FP16, "f32": DT_F32}
+
+
+def dt(code):
+    return _NAMES[code] if isinstance(code, str) else int(code)
+
+
+# ---------------------------------------------------------------- dtype plumbing
+def to_f32(a: np.ndarray, dtype) -> np.ndarray:
+    """Exact up-conversion of a stored tensor to float32."""
+    d = dt(dtype)
+    if d == DT_F32:
+        return np.asarray(a, dtype=np.float32)
+    a = np.asarray(a, dtype=np.uint16)
+    if d == DT_FP16:
+        return a.view(np.float16).astype(np.float32)
+    return (a.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def from_f32(t: np.ndarray, dtype) -> np.ndarray:
+    """Round-to-nearest-even down-conversion; bf16 keeps NaN a (quiet) NaN like v_cvt_pk_bf16_f32."""
+    d = dt(dtype)
+    t = np.asarray(t, dtype=np.float32)
+    if d == DT_F32:
+        return t.copy()
+    if d == DT_FP16:
+        with np.errstate(over="ignore"):
+            return t.astype(np.float16).view(np.uint16)
+    u = t.view(np.uint32)
+    rounded = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    nan = np.isnan(t)
+    quiet = ((u >> np.uint32(16)) | np.uint32(0x0040)).astype(np.uint16)
+    return np.where(nan, quiet, rounded)
+
+
+# ---------------------------------------------------------------- QSPEC stages
+def quantize(x: np.ndarray, dtype, reduce_axis: int):
+    """QSPEC Q1-Q6. reduce_axis = 1 (per-token rows) or 0 (per-channel columns)."""
+    xf = to_f32(x, dtype)
+    assert xf.ndim == 2
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        ax = np.abs(xf)
+        if xf.shape[reduce_axis] == 0:
+            amax = np.zeros(xf.shape[1 - reduce_axis], np.float32)
+        else:
+            amax = np.fmax.reduce(ax, axis=reduce_axis)        # NaN-ignoring max (Q2)
+            amax = np.where(np.isnan(amax), np.float32(0), amax).astype(np.float32)
+        scale = (amax / np.float32(127.0)).astype(np.float32)    # Q3 true division
+        scale = np.where(amax == 0, np.float32(1.0), scale).astype(np.float32)
+        s = np.expand_dims(scale, reduce_axis)
+        t = np.rint((xf / s).astype(np.float32))                 # Q4 true division + RNE
+        t = np.where(np.isnan(t), np.float32(0), t)              # Q5 NaN -> 0
+        q = np.clip(t, -128.0, 127.0).astype(np.int8)            # Q6
+    return q, scale
+
+
+def dequantize(q: np.ndarray, scale: np.ndarray, reduce_axis: int, out_dtype):
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = q.astype(np.float32) * np.expand_dims(scale.astype(np.float32), reduce_axis)
+    return from_f32(t.astype(np.float32), out_dtype)
+
+
+def gemm_s8s8s32(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """acc[m,n] = sum_k a[m,k]*b[n,k], exact (int32 wraps like the hardware would; never reached
+    for K <= 131071)."""
+    if a.shape[1] == 0:
+        return np.zeros((a.shape[0], b.shape[0]), np.int32)
+    # float64 BLAS is exact here: |acc| <= 128*128*K < 2^53 for any practical K.
+    acc = a.astype(np.float64) @ b.astype(np.float64).T
+    return acc.astype(np.int64).astype(np.int32)
+
+
+def epilogue(acc: np.ndarray, xs: np.ndarray, ws: np.ndarray, bias, out_dtype):
+    """QSPEC E1-E4: (f32(acc)*xs[m])*ws[n] (+f32(bias[n])), each op rounded separately."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = acc.astype(np.float32)                               # RNE int32 -> f32
+        t = (t * xs.astype(np.float32)[:, None]).astype(np.float32)
+        t = (t * ws.astype(np.float32)[None, :]).astype(np.float32)
+        if bias is not None:
+            t = (t + to_f32(bias, out_dtype)[None, :]).astype(np.float32)
+    return from_f32(t, out_dtype)
+
+
+def qlinear(x, dtype, wq, ws, bias=None):
+    xq, xs = quantize(x, dtype, 1)
+    acc = gemm_s8s8s32(xq, wq)
+    y = epilogue(acc, xs, ws, bias, dtype)
+    return y, xq, xs, acc

@@ -1,0 +1,148 @@
+/* TEST INFRASTRUCTURE — plain-C restatement of QSPEC v1.
+ *
+ * Parity status: PARITY UNPINNED BY THE REFERENCE.  /root/reference holds no source, tests or
+ * golden vectors for the dynamic-int8 linear path (only /root/reference/CODE_OF_CONDUCT.md:1-80),
+ * so no function below can cite a reference file:line.  Each function instead cites the QSPEC
+ * clause it follows; the integer GEMM restates torch._int_mm (aten::_int_mm, third-party PyTorch
+ * 2.10.0, git 449b1768), which is exact integer arithmetic.  Pinned against tests/golden/ (made
+ * by oracle/torch_ref.py around torch._int_mm) in tests/test_oracle.py.
+ *
+ * Build: oracle/Makefile -> oracle/liboracle.so   (gcc -O2 -ffp-contract=off -fopenmp; NO -ffast-math)
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+enum { OQ_BF16 = 0, OQ_FP16 = 1, OQ_F32 = 2 };
+
+/* ---- dtype plumbing (exact up-conversion, RNE down-conversion) ---- */
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f;
+}
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if (f != f) return (uint16_t)((u >> 16) | 0x0040u);           /* keep NaN a quiet NaN */
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);    /* round-to-nearest-even */
+}
+/* IEEE binary16 <-> binary32 by hand (gcc 11 has no _Float16 on x86-64) */
+static inline float fp16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu, u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } m &= 0x3FFu; u = sign | ((uint32_t)(113 - sh) << 23) | (m << 13); }
+    } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+static inline uint16_t f32_to_fp16(float f) {        /* round-to-nearest-even, overflow -> inf */
+    uint32_t u; memcpy(&u, &f, 4);
+    uint16_t sign = (uint16_t)((u >> 16) & 0x8000u); uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint16_t)(sign | 0x7E00u | ((a >> 13) & 0x3FFu));   /* NaN */
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                          /* >= 65520 -> inf */
+    if (a < 0x33000001u) return sign;                                                 /* <= 2^-25 -> 0 */
+    int32_t e = (int32_t)(a >> 23) - 127; uint32_t m = (a & 0x7FFFFFu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                                    /* subnormal: extra shift */
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    uint32_t he = (e < -14) ? 0u : (uint32_t)(e + 15);
+    /* q holds the implicit bit for normals: adding (he-1)<<10 lets a mantissa carry bump the exponent */
+    uint32_t out = (e < -14) ? q : (((he - 1u) << 10) + q);
+    return (uint16_t)(sign | out);
+}
+
+static inline float load_f32(const void* p, int dtype, int64_t i) {
+    switch (dtype) {
+        case OQ_BF16: return bf16_to_f32(((const uint16_t*)p)[i]);
+        case OQ_FP16: return fp16_to_f32(((const uint16_t*)p)[i]);
+        default:      return ((const float*)p)[i];
+    }
+}
+static inline void store_f32(void* p, int dtype, int64_t i, float v) {
+    switch (dtype) {
+        case OQ_BF16: ((uint16_t*)p)[i] = f32_to_bf16(v); break;
+        case OQ_FP16: ((uint16_t*)p)[i] = f32_to_fp16(v); break;
+        default:      ((float*)p)[i] = v; break;
+    }
+}
+
+/* QSPEC Q2: NaN-ignoring running max of |x| (a compare that is false for any NaN, quiet or signalling) */
+static inline float amax_step(float amax, float v) { float a = fabsf(v); return a > amax ? a : amax; }
+/* QSPEC Q3: scale = amax/127 (true division), 1.0 when amax == 0 */
+static inline float scale_of(float amax) { return amax == 0.0f ? 1.0f : amax / 127.0f; }
+/* QSPEC Q4-Q6: q = clamp(rne(x/scale)), NaN -> 0 */
+static inline int8_t code_of(float x, float scale) {
+    float t = rintf(x / scale);            /* default rounding mode: half-to-even */
+    if (t != t) return 0;
+    if (t > 127.0f) t = 127.0f;
+    if (t < -128.0f) t = -128.0f;
+    return (int8_t)t;
+}
+
+/* QSPEC quantize, reduce over columns (per-token). x[rows, cols] with leading dimension ldx. */
+void oq_quant_rowwise(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ldx,
+                      int8_t* q, int64_t ldq, float* scale) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float amax = 0.0f;
+        for (int64_t c = 0; c < cols; ++c) amax = amax_step(amax, load_f32(x, dtype, r * ldx + c));
+        float s = scale_of(amax);
+        scale[r] = s;
+        for (int64_t c = 0; c < cols; ++c) q[r * ldq + c] = code_of(load_f32(x, dtype, r * ldx + c), s);
+    }
+}
+
+/* QSPEC quantize, reduce over rows (per-channel of a row-major [rows, cols] matrix). */
+void oq_quant_colwise(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ldx,
+                      int8_t* q, int64_t ldq, float* scale) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < cols; ++c) {
+        float amax = 0.0f;
+        for (int64_t r = 0; r < rows; ++r) amax = amax_step(amax, load_f32(x, dtype, r * ldx + c));
+        scale[c] = scale_of(amax);
+    }
+    #pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) q[r * ldq + c] = code_of(load_f32(x, dtype, r * ldx + c), scale[c]);
+}
+
+/* QSPEC dequantize: out = cast_rne(f32(q) * scale[kept axis]); axis = reduced axis (1 rows-scale, 0 cols-scale) */
+void oq_dequant(const int8_t* q, int64_t ldq, const float* scale, int axis, int64_t rows, int64_t cols,
+                void* out, int64_t ldo, int out_dtype) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c)
+            store_f32(out, out_dtype, r * ldo + c, (float)q[r * ldq + c] * (axis == 0 ? scale[c] : scale[r]));
+}
+
+/* restates torch._int_mm(a, b.t()): c[m,n] = sum_k a[m,k]*b[n,k], exact int32 */
+void oq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
+                     int32_t* c, int64_t ldc, int64_t M, int64_t N, int64_t K) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t n = 0; n < N; ++n) {
+            const int8_t* ar = a + m * lda; const int8_t* br = b + n * ldb;
+            int32_t acc = 0;
+            for (int64_t k = 0; k < K; ++k) acc += (int32_t)ar[k] * (int32_t)br[k];
+            c[m * ldc + n] = acc;
+        }
+}
+
+/* QSPEC epilogue E1-E4 on top of the exact accumulator */
+void oq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
+                   const int8_t* b, int64_t ldb, const float* b_scale,
+                   const void* bias, void* y, int64_t ldy, int out_dtype,
+                   int64_t M, int64_t N, int64_t K) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t n = 0; n < N; ++n) {
+            const int8_t* ar = a + m * lda; const int8_t* br = b + n * ldb;
+            int32_t acc = 0;
+            for (int64_t k = 0; k < K; ++k) acc += (int32_t)ar[k] * (int32_t)br[k];
+            float t = (float)acc;              /* E1: RNE int32 -> f32 */
+            t = t * a_scale[m];                /* E2: row scale first  */
+            t = t * b_scale[n];                /* E3: then column scale */
+            if (bias) t = t + load_f32(bias, out_dtype, n);   /* E4: separate rounded add */
+            store_f32(y, out_dtype, m * ldy + n, t);
+        }
+}

@@ -1,0 +1,59 @@
+"""TEST INFRASTRUCTURE — QSPEC v1 as plain torch CPU ops around ``torch._int_mm``.
+
+Parity status: *parity unpinned by the reference* — ``/root/reference`` contains no source for
+this path (only ``/root/reference/CODE_OF_CONDUCT.md:1-80``), so nothing here can cite a reference
+``file:line``. What is followed instead:
+
+* the integer GEMM is ``torch._int_mm`` itself (``aten::_int_mm(Tensor self, Tensor mat2)``), the
+  primitive ``BASELINE.json`` → ``north_star`` names as the CPU oracle;
+* every float stage follows QSPEC v1 (``DESIGN.md`` §2), op for op.
+
+This module is what "protoquant's own CPU path" means in ``bench.py``'s ``cpu_baseline`` leg and what
+``oracle/gen_golden.py`` runs to produce ``tests/golden/*.npz``.  It must only ever be imported from
+``tests/``, ``bench.py`` (cpu_baseline) and ``oracle/gen_golden.py`` — never from ``protoquant_amd``.
+"""
+from __future__ import annotations
+
+import torch
+
+QMAX = 127.0
+
+
+def quantize_ref(x: torch.Tensor, reduce_dim: int):
+    """QSPEC quantize. ``reduce_dim`` is the axis the amax is taken over (-1/1: per-token rows,
+    0: per-channel columns of a row-major matrix).  Returns (int8 codes, fp32 scale vector)."""
+    assert x.dim() == 2 and x.device.type == "cpu"
+    xf = x.to(torch.float32)                                   # exact up-conversion
+    amax = xf.abs().amax(dim=reduce_dim)                       # exact
+    scale = amax / torch.tensor(QMAX, dtype=torch.float32)     # true fp32 division
+    scale = torch.where(amax == 0, torch.ones_like(scale), scale)   # zero guard (QSPEC Q3)
+    s = scale.unsqueeze(reduce_dim)
+    q = torch.round(xf / s)                                    # true division, half-to-even
+    q = torch.clamp(q, -128.0, 127.0).to(torch.int8)
+    return q, scale
+
+
+def dequantize_ref(q: torch.Tensor, scale: torch.Tensor, reduce_dim: int, dtype: torch.dtype):
+    """QSPEC dequantize: cast_rne(f32(q) * scale broadcast on the kept axis)."""
+    return (q.to(torch.float32) * scale.unsqueeze(reduce_dim)).to(dtype)
+
+
+def int_gemm_ref(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
+    """acc[m,n] = sum_k xq[m,k] * wq[n,k]  ==  torch._int_mm(xq, wq.t())."""
+    return torch._int_mm(xq, wq.t())
+
+
+def epilogue_ref(acc: torch.Tensor, xs: torch.Tensor, ws: torch.Tensor, bias, dtype: torch.dtype):
+    """QSPEC epilogue: (f32(acc) * xs[m]) * ws[n] (+ f32(bias[n])) -> cast_rne(dtype)."""
+    t = (acc.to(torch.float32) * xs[:, None]) * ws[None, :]
+    if bias is not None:
+        t = t + bias.to(torch.float32)[None, :]
+    return t.to(dtype)
+
+
+def qlinear_ref(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None):
+    """Full dynamic-int8 linear for a 2-D activation. Returns (y, xq, xs, acc)."""
+    xq, xs = quantize_ref(x, 1)
+    acc = int_gemm_ref(xq, wq)
+    y = epilogue_ref(acc, xs, ws, bias, x.dtype)
+    return y, xq, xs, acc

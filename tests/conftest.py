@@ -1,0 +1,32 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+DT_CODE = {"bf16": 0, "fp16": 1, "f32": 2}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(path):
+    z = np.load(path)
+    d = {k: z[k] for k in z.files}
+    d["name"] = os.path.basename(path)[:-4]
+    d["dtype"] = str(d["dtype"])
+    d["code"] = DT_CODE[d["dtype"]]
+    d.setdefault("bias", None)
+    return d
+
+
+@pytest.fixture(params=GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def golden(request):
+    return load_golden(request.param)

@@ -1,0 +1,95 @@
+"""CPU: pins the oracle restatements (numpy + plain C) to the committed golden vectors, which were
+produced by oracle/torch_ref.py around torch._int_mm (the primitive BASELINE.json names).  The
+reference itself has no tests/fixtures for this path (/root/reference/CODE_OF_CONDUCT.md:1-80 only)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as C
+from oracle import qspec_numpy as Q
+
+
+def eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    assert np.array_equal(a, b), f"{np.count_nonzero(a != b)} of {a.size} differ"
+
+
+def test_numpy_oracle_matches_golden(golden):
+    g = golden
+    xq, xs = Q.quantize(g["x"], g["code"], 1)
+    eq(xq, g["xq"]); eq(xs, g["xs"])
+    wq, ws = Q.quantize(g["w"], g["code"], 1)
+    eq(wq, g["wq"]); eq(ws, g["ws"])
+    cq, cs = Q.quantize(g["x"], g["code"], 0)
+    eq(cq, g["x_colq"]); eq(cs, g["x_cols"])
+    acc = Q.gemm_s8s8s32(xq, wq)
+    eq(acc, g["acc"])
+    eq(Q.epilogue(acc, xs, ws, g["bias"], g["code"]), g["y"])
+    eq(Q.dequantize(xq, xs, 1, g["code"]), g["x_deq"])
+    eq(Q.dequantize(cq, cs, 0, g["code"]), g["x_coldeq"])
+
+
+def test_c_oracle_matches_golden(golden):
+    g = golden
+    xq, xs = C.quant_rowwise(g["x"], g["code"])
+    eq(xq, g["xq"]); eq(xs, g["xs"])
+    wq, ws = C.quant_rowwise(g["w"], g["code"])
+    eq(wq, g["wq"]); eq(ws, g["ws"])
+    cq, cs = C.quant_colwise(g["x"], g["code"])
+    eq(cq, g["x_colq"]); eq(cs, g["x_cols"])
+    eq(C.gemm_s8s8s32(xq, wq), g["acc"])
+    eq(C.qlinear_s8(xq, xs, wq, ws, g["bias"], g["code"]), g["y"])
+    eq(C.dequant(xq, xs, 1, g["code"]), g["x_deq"])
+    eq(C.dequant(cq, cs, 0, g["code"]), g["x_coldeq"])
+
+
+def test_int_gemm_is_exact_integer_arithmetic(golden):
+    g = golden
+    acc64 = g["xq"].astype(np.int64) @ g["wq"].astype(np.int64).T
+    assert np.array_equal(acc64, g["acc"].astype(np.int64))
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_c_vs_numpy_on_special_values(dtype):
+    """NaN / Inf / signalling-NaN / subnormal policy (QSPEC Q2,Q5): the two restatements agree."""
+    rng = np.random.default_rng(5)
+    xf = rng.standard_normal((9, 40)).astype(np.float32)
+    xf[1, 3] = np.nan; xf[2, 5] = np.inf; xf[3, :] = 0; xf[4, 0] = -np.inf; xf[4, 1] = np.nan
+    xf[5, :] = 1e-41
+    x = Q.from_f32(xf, dtype)
+    if dtype != 2:
+        x[6, 2] = 0x7F81 if dtype == 0 else 0x7C01          # signalling NaN bit pattern
+    for axis, cfn in ((1, C.quant_rowwise), (0, C.quant_colwise)):
+        qn, sn = Q.quantize(x, dtype, axis)
+        qc, sc = cfn(x, dtype)
+        eq(qn, qc); eq(sn, sc)
+        eq(Q.dequantize(qn, sn, axis, dtype), C.dequant(qc, sc, axis, dtype))
+
+
+def test_fp16_bf16_rounding_exhaustive():
+    allh = np.arange(65536, dtype=np.uint16)
+    for dtype in (0, 1):
+        f = Q.to_f32(allh, dtype)
+        mid = (f + np.nextafter(f, np.float32(np.inf))) / np.float32(2)
+        for v in (f, np.nextafter(f, np.float32(np.inf)), mid):
+            v = v[np.isfinite(v)].astype(np.float32)
+            a = Q.from_f32(v, dtype).reshape(1, -1)
+            b = C.dequant(np.ones((1, v.size), np.int8), v, 0, dtype)
+            eq(a, b)
+
+
+def test_quant_properties():
+    rng = np.random.default_rng(7)
+    for shape in ((1, 1), (3, 17), (64, 300), (0, 5), (5, 0)):
+        x = (rng.standard_normal(shape) * 3).astype(np.float32)
+        q, s = Q.quantize(x, 2, 1)
+        assert q.shape == shape and s.shape == (shape[0],)
+        assert np.all(s > 0)
+        if x.size:
+            assert np.abs(q.astype(np.int32)).max() <= 127
+            err = np.abs(x - q.astype(np.float32) * s[:, None])
+            assert np.all(err <= s[:, None] * 0.5 * (1 + 1e-6))
+            qc, sc = C.quant_rowwise(x, 2)
+            eq(q, qc); eq(s, sc)
