@@ -1,0 +1,87 @@
+/* pq_hip.h — C-ABI of libpq_hip.so: the MI355X (gfx950) dynamic-int8 linear hot path.
+ *
+ * This is the drop-in boundary.  The reference's operator interface for this path
+ * is the Python API BASELINE.json names (QTensor, quantize(), dequantize(), qlinear); its source is
+ * absent from the mount (/root/reference holds only CODE_OF_CONDUCT.md:1-80), so each entry point
+ * cites the contract clause / primitive it replaces instead of a reference file:line.
+ *
+ * Conventions
+ *  - plain pointers + sizes; every buffer is CALLER-OWNED DEVICE memory on the current HIP device;
+ *    the library never allocates, frees, copies to host or synchronises.
+ *  - stream-ordered and asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*;
+ *    NULL = the null stream).  Safe to capture into a hipGraph.
+ *  - every function returns a pq_status; pq_last_error() gives the thread-local message of the last
+ *    failing call on this thread.  Nothing throws across the ABI.
+ *  - matrices are row-major with explicit leading dimensions in ELEMENTS.
+ *  - dtype codes: 0 = bf16, 1 = fp16, 2 = f32.
+ *  - numeric contract: QSPEC v1.  int32 accumulators are exact; float stages are
+ *    IEEE binary32, round-to-nearest-even, no contraction, true division.
+ */
+#ifndef PQ_HIP_H
+#define PQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ_ABI_VERSION 1
+
+typedef enum {
+    PQ_OK = 0,
+    PQ_ERR_BAD_ARG = 1,        /* null pointer, negative size, ld too small, unknown dtype/axis */
+    PQ_ERR_BAD_ALIGN = 2,      /* reserved: every alignment is currently served by a generic path */
+    PQ_ERR_LAUNCH = 3,         /* hipGetLastError() after a launch was not hipSuccess */
+    PQ_ERR_UNIMPLEMENTED = 4,
+    PQ_ERR_WORKSPACE = 5,      /* caller-provided workspace smaller than pq_*_workspace_bytes() */
+    PQ_ERR_COMM = 6            /* RCCL error (multi-GPU entry points) */
+} pq_status;
+
+enum { PQ_BF16 = 0, PQ_FP16 = 1, PQ_F32 = 2 };
+
+/* ABI version of the loaded library (== PQ_ABI_VERSION it was built with). */
+int32_t pq_version(void);
+/* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
+const char* pq_last_error(void);
+
+/* K1 — per-token dynamic symmetric int8 quantisation: replaces quantize(x) of the contract for an
+ * activation x[rows, cols] (amax over cols).  q[rows, cols] int8, scale[rows] f32.   QSPEC Q1-Q6. */
+int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x,
+                         int8_t* q, int64_t ld_q, float* scale, void* stream);
+
+/* K2 — per-channel quantisation of a row-major matrix along its strided axis (amax over rows):
+ * replaces quantize(W) for a [K, N]-stored weight.  scale[cols] f32.  Three stream-ordered launches
+ * (amax, encode, finalise); `scale` doubles as the amax scratch — no workspace.   QSPEC Q1-Q6. */
+int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x,
+                         int8_t* q, int64_t ld_q, float* scale, void* stream);
+
+/* dequantize(): out[r,c] = cast_rne(f32(q[r,c]) * scale[axis==0 ? c : r]).  `axis` is the axis the
+ * scale was reduced over (1: one scale per row, 0: one scale per column).   QSPEC D1. */
+int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis,
+                   int64_t rows, int64_t cols, void* out, int64_t ld_out, int32_t out_dtype, void* stream);
+
+/* K3 debug/parity twin — c[M,N] = sum_k a[M,k] * b[N,k], exact int32: the drop-in for
+ * torch._int_mm(a, b.t()) (aten::_int_mm), which BASELINE.json names as the CPU oracle. */
+int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
+                        int32_t* c, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* K3+K4 — int8 GEMM on v_mfma_i32_*_i8 with the fused dequant epilogue:
+ *   y[m,n] = cast_rne_out((f32(acc[m,n]) * a_scale[m]) * b_scale[n] (+ f32(bias[n])))   QSPEC E1-E4.
+ * bias is nullable and has the output dtype.  workspace may be NULL when
+ * pq_qlinear_workspace_bytes(M,N,K) == 0 (always, in this version). */
+int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
+                      const int8_t* b, int64_t ldb, const float* b_scale,
+                      const void* bias, void* y, int64_t ldy, int32_t out_dtype,
+                      int64_t M, int64_t N, int64_t K,
+                      void* workspace, size_t workspace_bytes, void* stream);
+size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* Name of the GEMM kernel variant the dispatcher would pick for this problem (static string). */
+const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQ_HIP_H */

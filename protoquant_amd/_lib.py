@@ -1,0 +1,95 @@
+"""ctypes binding of libpq_hip.so (include/pq_hip.h).  There is NO fallback: if the HIP library is
+missing or fails to load, every entry point raises — the product never routes through oracle/ or a
+CPU/eager path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: libpq_hip.so shares torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpq_hip.so")
+ABI_VERSION = 1
+
+PQ_BF16, PQ_FP16, PQ_F32 = 0, 1, 2
+_DT = {torch.bfloat16: PQ_BF16, torch.float16: PQ_FP16, torch.float32: PQ_F32}
+
+EXPORTS = (
+    "pq_version", "pq_last_error", "pq_quant_rowwise", "pq_quant_colwise", "pq_dequant",
+    "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes", "pq_gemm_variant_name",
+)
+
+_lib = None
+i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+
+
+class PQError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libpq_hip.so once; raise loudly when it is absent (build it with __graft_entry__.build()
+    or `make -C protoquant_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PQError(f"{LIB_PATH} not found: build it with `make -C protoquant_amd/csrc` "
+                      "(protoquant_amd has no CPU/eager fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    L.pq_version.restype = i32
+    L.pq_last_error.restype = ctypes.c_char_p
+    L.pq_gemm_variant_name.restype = ctypes.c_char_p
+    L.pq_gemm_variant_name.argtypes = [i64, i64, i64, i64, i64]
+    L.pq_qlinear_workspace_bytes.restype = sz
+    L.pq_qlinear_workspace_bytes.argtypes = [i64, i64, i64]
+    L.pq_quant_rowwise.restype = i32
+    L.pq_quant_rowwise.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, vp]
+    L.pq_quant_colwise.restype = i32
+    L.pq_quant_colwise.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, vp]
+    L.pq_dequant.restype = i32
+    L.pq_dequant.argtypes = [vp, i64, vp, i32, i64, i64, vp, i64, i32, vp]
+    L.pq_gemm_s8s8s32.restype = i32
+    L.pq_gemm_s8s8s32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]
+    L.pq_qlinear_s8.restype = i32
+    L.pq_qlinear_s8.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64, i64, vp, sz, vp]
+    if L.pq_version() != ABI_VERSION:
+        raise PQError(f"libpq_hip.so ABI {L.pq_version()} != expected {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise PQError(f"{what} failed (status {status}): {lib().pq_last_error().decode()}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"protoquant_amd supports bf16/fp16/fp32 tensors, got {dt}") from None
+
+
+def require_gpu(t: torch.Tensor, name: str):
+    if t.device.type != "cuda":
+        raise PQError(f"{name} is on {t.device}: protoquant_amd runs on MI355X (HIP) only and has no "
+                      "CPU fallback — move the tensor to the GPU")
+
+
+def stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def row_major_2d(t: torch.Tensor) -> torch.Tensor:
+    """A 2-D view whose last dim is contiguous (stride(1) == 1); copies only if it must."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor")
+    if t.shape[1] > 0 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)

@@ -1,0 +1,165 @@
+// pq_api.hip — the C-ABI of libpq_hip.so (include/pq_hip.h): argument validation, variant selection,
+// launches, status codes.  No allocation, no synchronisation, no host copies: graph-capturable.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gemm_epilogue.h"
+
+namespace pq {
+template <int DT> void quant_rowwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template <int DT> void quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
+template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT, int SHAPE> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
+}  // namespace pq
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int32_t check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return PQ_OK;
+}
+
+enum Variant { V_AUTO = 0, V_GENERIC, V_PP256_16, V_PP256_32 };
+
+Variant forced_variant() {
+    const char* e = getenv("PQ_FORCE_VARIANT");
+    if (!e || !*e) return V_AUTO;
+    if (!strcmp(e, "generic")) return V_GENERIC;
+    if (!strcmp(e, "pp256_16")) return V_PP256_16;
+    if (!strcmp(e, "pp256_32")) return V_PP256_32;
+    return V_AUTO;
+}
+
+Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    const bool ok = pq::gemm_fast_eligible(a, lda, b, ldb, M, N, K);
+    const Variant f = forced_variant();
+    if (f == V_GENERIC || !ok) return V_GENERIC;
+    if (f != V_AUTO) return f;
+    if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
+    return V_PP256_16;
+}
+
+template <int OUT>
+void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
+              int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    if (v == V_PP256_16) pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_PP256_32) {
+        if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32>(a, lda, b, ldb, epi, M, N, K, st);
+        else pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
+    } else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
+}
+
+bool bad_mat(const void* p, int64_t rows, int64_t cols, int64_t ld) {
+    return rows < 0 || cols < 0 || ld < cols || (rows > 0 && cols > 0 && p == nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pq_version(void) { return PQ_ABI_VERSION; }
+const char* pq_last_error(void) { return g_err; }
+
+int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, int8_t* q,
+                         int64_t ld_q, float* scale, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise: unknown dtype %d", dtype);
+    if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::quant_rowwise_dispatch<PQ_BF16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        case PQ_FP16: pq::quant_rowwise_dispatch<PQ_FP16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        default: pq::quant_rowwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+    }
+    return check_launch("pq_quant_rowwise");
+}
+
+int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, int8_t* q,
+                         int64_t ld_q, float* scale, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_colwise: unknown dtype %d", dtype);
+    if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (cols > 0 && !scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_quant_colwise: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
+    if (cols == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::quant_colwise_dispatch<PQ_BF16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        case PQ_FP16: pq::quant_colwise_dispatch<PQ_FP16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        default: pq::quant_colwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+    }
+    return check_launch("pq_quant_colwise");
+}
+
+int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis, int64_t rows, int64_t cols,
+                   void* out, int64_t ld_out, int32_t out_dtype, void* stream) {
+    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_dequant: unknown dtype %d", out_dtype);
+    if (axis != 0 && axis != 1) return fail(PQ_ERR_BAD_ARG, "pq_dequant: axis must be 0 or 1, got %d", axis);
+    if (bad_mat(q, rows, cols, ld_q) || bad_mat(out, rows, cols, ld_out) || (rows > 0 && cols > 0 && !scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_dequant: bad matrix (rows=%lld cols=%lld)", (long long)rows, (long long)cols);
+    if (rows == 0 || cols == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (out_dtype) {
+        case PQ_BF16: pq::dequant_dispatch<PQ_BF16>(q, ld_q, scale, axis, rows, cols, out, ld_out, st); break;
+        case PQ_FP16: pq::dequant_dispatch<PQ_FP16>(q, ld_q, scale, axis, rows, cols, out, ld_out, st); break;
+        default: pq::dequant_dispatch<PQ_F32>(q, ld_q, scale, axis, rows, cols, out, ld_out, st); break;
+    }
+    return check_launch("pq_dequant");
+}
+
+int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, int32_t* c, int64_t ldc,
+                        int64_t M, int64_t N, int64_t K, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(c, M, N, ldc))
+        return fail(PQ_ERR_BAD_ARG, "pq_gemm_s8s8s32: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldc);
+    if (M == 0 || N == 0) return PQ_OK;
+    pq::EpiArgs epi{nullptr, nullptr, nullptr, c, ldc};
+    run_gemm<pq::OUT_I32>(pick_variant(a, lda, b, ldb, M, N, K), a, lda, b, ldb, epi, M, N, K, static_cast<hipStream_t>(stream));
+    return check_launch("pq_gemm_s8s8s32");
+}
+
+size_t pq_qlinear_workspace_bytes(int64_t, int64_t, int64_t) { return 0; }
+
+int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
+                      const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M,
+                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: unknown dtype %d", out_dtype);
+    if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(y, M, N, ldy) ||
+        (M > 0 && !a_scale) || (N > 0 && !b_scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldy=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldy);
+    if (M == 0 || N == 0) return PQ_OK;
+    pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy};
+    const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (out_dtype) {
+        case PQ_BF16: run_gemm<PQ_BF16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+        case PQ_FP16: run_gemm<PQ_FP16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+        default: run_gemm<PQ_F32>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+    }
+    return check_launch("pq_qlinear_s8");
+}
+
+const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    // alignment of the pointers is unknown here: assume 16-byte aligned bases
+    switch (pick_variant(reinterpret_cast<const int8_t*>(16), lda, reinterpret_cast<const int8_t*>(16), ldb, M, N, K)) {
+        case V_PP256_16: return "pp256_16x16x64";
+        case V_PP256_32: return "pp256_32x32x32";
+        default: return "generic64";
+    }
+}
+
+}  // extern "C"

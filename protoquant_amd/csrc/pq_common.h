@@ -1,0 +1,80 @@
+// pq_common.h — shared device helpers for the gfx950 dynamic-int8 linear path (QSPEC v1).
+// gfx950 only: 64-wide wavefronts are hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pq_hip.h"
+
+namespace pq {
+
+constexpr int kWave = 64;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- element types
+// DT: 0 bf16, 1 fp16 (both stored as 16-bit patterns), 2 f32.
+template <int DT> struct Elem;
+template <> struct Elem<PQ_BF16> {
+    using store_t = uint16_t;
+    static constexpr int kBytes = 2;
+    __device__ static __forceinline__ float to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+    // plain cast: v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
+    __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+};
+template <> struct Elem<PQ_FP16> {
+    using store_t = uint16_t;
+    static constexpr int kBytes = 2;
+    __device__ static __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+};
+template <> struct Elem<PQ_F32> {
+    using store_t = float;
+    static constexpr int kBytes = 4;
+    __device__ static __forceinline__ float to_f32(float f) { return f; }
+    __device__ static __forceinline__ float from_f32(float f) { return f; }
+};
+
+// ---------------------------------------------------------------- QSPEC scalar rules
+// Q2: NaN-ignoring running max of |x| (compare is false for every NaN).
+__device__ __forceinline__ float amax_step(float amax, float v) {
+    float a = __builtin_fabsf(v);
+    return a > amax ? a : amax;
+}
+// Q3: scale = amax / 127 (IEEE division), 1 when amax == 0.
+__device__ __forceinline__ float scale_of(float amax) { return amax == 0.0f ? 1.0f : amax / 127.0f; }
+// Q4-Q6: code = clamp(rne(x / scale), -128, 127), NaN -> 0.   True division: never x * (1/scale).
+__device__ __forceinline__ int code_of(float x, float scale) {
+    float t = __builtin_rintf(x / scale);
+    t = (t != t) ? 0.0f : t;
+    t = t > 127.0f ? 127.0f : t;
+    t = t < -128.0f ? -128.0f : t;
+    return (int)t;
+}
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)d << 24);
+}
+
+// wave-wide max of non-negative floats (all 64 lanes get the result)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// E1-E4 epilogue value for one accumulator.
+__device__ __forceinline__ float epilogue_val(int acc, float a_scale, float b_scale) {
+    float t = (float)acc;      // v_cvt_f32_i32: RNE
+    t = t * a_scale;           // row scale first
+    t = t * b_scale;           // then column scale
+    return t;
+}
+
+}  // namespace pq

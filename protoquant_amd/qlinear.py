@@ -1,0 +1,115 @@
+"""qlinear: the nn.Linear replacement of the contract (BASELINE.json north_star) + swap_linears().
+
+forward(x[..., K]) = K1 row-quant(x) -> K3 s8xs8->s32 MFMA GEMM -> K4 fused (row-scale x col-scale
+(+bias)) epilogue, all inside libpq_hip.so.  Weights are quantised once, per output channel, when
+the module is built.  Reference definitions are absent from the mount (/root/reference holds only
+CODE_OF_CONDUCT.md:1-80); semantics follow QSPEC v1."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .qtensor import QTensor, quantize
+
+
+def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
+    """acc[M,N] = xq[M,K] . wq[N,K]^T, exact int32 — the GPU twin of torch._int_mm(xq, wq.t())."""
+    L.require_gpu(xq, "int_mm(xq)")
+    xq, wq = L.row_major_2d(xq), L.row_major_2d(wq)
+    M, K = xq.shape
+    N, K2 = wq.shape
+    if K != K2 or xq.dtype != torch.int8 or wq.dtype != torch.int8:
+        raise ValueError("int_mm expects int8 [M,K] and int8 [N,K]")
+    acc = torch.empty((M, N), dtype=torch.int32, device=xq.device)
+    with torch.cuda.device(xq.device):
+        L.check(L.lib().pq_gemm_s8s8s32(xq.data_ptr(), L.ld(xq), wq.data_ptr(), L.ld(wq), acc.data_ptr(), max(N, 1),
+                                        M, N, K, L.stream_ptr(xq)), "int_mm")
+    return acc
+
+
+def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
+               out: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused int8 GEMM + dequant epilogue on pre-quantised operands (C-ABI pq_qlinear_s8)."""
+    L.require_gpu(xq, "qlinear_s8(xq)")
+    xq, wq = L.row_major_2d(xq), L.row_major_2d(wq)
+    M, K = xq.shape
+    N = wq.shape[0]
+    if wq.shape[1] != K:
+        raise ValueError(f"shape mismatch: x has K={K}, weight has K={wq.shape[1]}")
+    code = L.dtype_code(out_dtype)
+    if bias is not None and bias.dtype != out_dtype:
+        bias = bias.to(out_dtype)
+    y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    with torch.cuda.device(xq.device):
+        L.check(L.lib().pq_qlinear_s8(xq.data_ptr(), L.ld(xq), xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, y.data_ptr(), L.ld(y), code,
+                                      M, N, K, None, 0, L.stream_ptr(xq)), "qlinear_s8")
+    return y
+
+
+class qlinear(nn.Module):
+    """Drop-in for nn.Linear with dynamic per-token int8 activations and per-channel int8 weights."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        dtype = dtype or torch.bfloat16
+        self.register_buffer("wq", torch.zeros((out_features, in_features), dtype=torch.int8, device=device))
+        self.register_buffer("ws", torch.ones((out_features,), dtype=torch.float32, device=device))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features,), dtype=dtype, device=device))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_linear(cls, lin: nn.Linear) -> "qlinear":
+        """Quantise lin.weight [N,K] per output channel on the GPU (kernel K1 over W's rows)."""
+        w = lin.weight.detach()
+        L.require_gpu(w, "qlinear.from_linear(weight)")
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.in_features, m.out_features = lin.in_features, lin.out_features
+        qw = quantize(w, axis=-1)
+        m.register_buffer("wq", qw.int_data)
+        m.register_buffer("ws", qw.scale)
+        if lin.bias is not None:
+            m.register_buffer("bias", lin.bias.detach().clone())
+        else:
+            m.bias = None
+        return m
+
+    @classmethod
+    def from_qtensor(cls, qw: QTensor, bias=None) -> "qlinear":
+        if qw.axis != 1 or qw.int_data.dim() != 2:
+            raise ValueError("weight QTensor must be [N,K] quantised per output channel (axis=-1)")
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.out_features, m.in_features = qw.int_data.shape
+        m.register_buffer("wq", qw.int_data)
+        m.register_buffer("ws", qw.scale)
+        if bias is not None:
+            m.register_buffer("bias", bias)
+        else:
+            m.bias = None
+        return m
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[-1] != self.in_features:
+            raise ValueError(f"qlinear: expected last dim {self.in_features}, got {x.shape[-1]}")
+        xq = quantize(x, axis=-1)
+        y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, x.dtype)
+        return y.reshape(*x.shape[:-1], self.out_features)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
+
+
+def swap_linears(model: nn.Module, predicate=None) -> nn.Module:
+    """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place."""
+    for name, child in list(model.named_children()):
+        if isinstance(child, nn.Linear) and (predicate is None or predicate(name, child)):
+            setattr(model, name, qlinear.from_linear(child))
+        else:
+            swap_linears(child, predicate)
+    return model

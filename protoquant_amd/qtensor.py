@@ -1,0 +1,83 @@
+"""QTensor + quantize()/dequantize(): the Python surface BASELINE.json's north_star names.
+
+The reference's own definitions are absent from the mount (/root/reference holds only
+CODE_OF_CONDUCT.md:1-80), so signatures are build-defined and numerics follow
+QSPEC v1.  All arithmetic happens in libpq_hip.so (HIP, gfx950)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass
+class QTensor:
+    """Dynamic symmetric int8 tensor: `int_data` (int8, original shape), `scale` (fp32, one per
+    kept index), `axis` = the reduced (quantised-over) axis of the 2-D view, `orig_dtype`."""
+    int_data: torch.Tensor
+    scale: torch.Tensor
+    axis: int
+    orig_dtype: torch.dtype
+    shape: torch.Size
+
+    def dequantize(self, dtype: torch.dtype | None = None) -> torch.Tensor:
+        return dequantize(self, dtype)
+
+    @property
+    def device(self):
+        return self.int_data.device
+
+    def to(self, device) -> "QTensor":
+        return QTensor(self.int_data.to(device), self.scale.to(device), self.axis, self.orig_dtype, self.shape)
+
+    def __repr__(self):
+        return (f"QTensor(shape={tuple(self.shape)}, axis={self.axis}, orig_dtype={self.orig_dtype}, "
+                f"device={self.int_data.device})")
+
+
+def _as_2d(x: torch.Tensor, axis: int):
+    """Collapse x to the 2-D matrix whose reduced axis is `axis` (last -> rows x cols reduce over
+    cols; first of a 2-D tensor -> reduce over rows)."""
+    nd = x.dim()
+    if nd == 0:
+        raise ValueError("quantize() needs at least 1 dimension")
+    a = axis % nd
+    if a == nd - 1:
+        return x.reshape(-1, x.shape[-1]), 1
+    if nd == 2 and a == 0:
+        return x, 0
+    raise ValueError("quantize(): axis must be the last axis, or axis 0 of a 2-D tensor")
+
+
+def quantize(x: torch.Tensor, axis: int = -1) -> QTensor:
+    """Dynamic symmetric int8 quantisation. axis=-1: per-token (one scale per row of the flattened
+    [..., C] tensor, kernel K1); axis=0 on a 2-D tensor: per-channel along the strided axis (K2)."""
+    L.require_gpu(x, "quantize(x)")
+    code = L.dtype_code(x.dtype)
+    x2, red = _as_2d(x, axis)
+    x2 = L.row_major_2d(x2)
+    rows, cols = x2.shape
+    q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+    scale = torch.empty((rows if red == 1 else cols,), dtype=torch.float32, device=x.device)
+    fn = L.lib().pq_quant_rowwise if red == 1 else L.lib().pq_quant_colwise
+    with torch.cuda.device(x.device):
+        L.check(fn(x2.data_ptr(), code, rows, cols, L.ld(x2), q.data_ptr(), max(cols, 1), scale.data_ptr(),
+                   L.stream_ptr(x)), "quantize")
+    return QTensor(q.reshape(x.shape), scale, red, x.dtype, x.shape)
+
+
+def dequantize(q: QTensor, dtype: torch.dtype | None = None) -> torch.Tensor:
+    """cast_rne(f32(int_data) * scale) along the kept axis -> `dtype` (default: the original dtype)."""
+    dtype = dtype or q.orig_dtype
+    L.require_gpu(q.int_data, "dequantize(q)")
+    code = L.dtype_code(dtype)
+    d2 = q.int_data.reshape(-1, q.shape[-1]) if q.axis == 1 else q.int_data
+    d2 = L.row_major_2d(d2)
+    rows, cols = d2.shape
+    out = torch.empty((rows, cols), dtype=dtype, device=d2.device)
+    with torch.cuda.device(d2.device):
+        L.check(L.lib().pq_dequant(d2.data_ptr(), L.ld(d2), q.scale.data_ptr(), q.axis, rows, cols, out.data_ptr(),
+                                   max(cols, 1), code, L.stream_ptr(d2)), "dequantize")
+    return out.reshape(q.shape)

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads (no GPU needed) and exports every symbol include/pq_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pq_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("pq_version", "pq_last_error", "pq_quant_rowwise", "pq_quant_colwise", "pq_dequant",
+              "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    for s in declared_symbols():
+        assert hasattr(L, s), f"libpq_hip.so does not export {s}"
+    assert set(_lib.EXPORTS) <= set(declared_symbols())
+    assert L.pq_version() == _lib.ABI_VERSION
+    assert L.pq_qlinear_workspace_bytes(4096, 4096, 4096) == 0
+    assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) in (b"pp256_16x16x64", b"pp256_32x32x32")
+    assert L.pq_gemm_variant_name(5, 7, 3, 3, 3) == b"generic64"
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad arguments are rejected before any HIP call."""
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    assert L.pq_quant_rowwise(None, 7, 1, 1, 1, None, 1, None, None) == 1
+    assert b"dtype" in L.pq_last_error()
+    assert L.pq_dequant(None, 4, None, 3, 2, 2, None, 2, 0, None) == 1
+    assert L.pq_gemm_s8s8s32(None, 1, None, 1, None, 1, -1, 1, 1, None) == 1
+    assert L.pq_qlinear_s8(None, 8, None, None, 8, None, None, None, 8, 9, 1, 1, 8, None, 0, None) == 1
+    assert L.pq_quant_rowwise(None, 0, 0, 16, 16, None, 16, None, None) == 0     # empty is a no-op
+
+
+def test_product_has_no_cpu_fallback_and_never_imports_oracle():
+    import torch
+    import protoquant_amd as pq
+    from protoquant_amd import _lib
+    with pytest.raises(_lib.PQError):
+        pq.quantize(torch.randn(2, 8))
+    with pytest.raises(_lib.PQError):
+        pq.qlinear(8, 8)(torch.randn(2, 8, dtype=torch.bfloat16))
+    pkg = os.path.join(ROOT, "protoquant_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f

@@ -1,0 +1,222 @@
+"""GPU parity (run with -m gpu on MI355X): the HIP path, called through the C-ABI, vs the committed
+golden vectors (torch._int_mm pipeline) and vs the oracle on seeded inputs.  Bar: bit-exact int8
+codes / fp32 scales / int32 accumulators, bit-identical bf16/fp16/f32 outputs (=> 1e-5 rel)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import qspec_numpy as Q
+from tests.gpu_util import TD, bits, same, to_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pq():
+    import protoquant_amd
+    from protoquant_amd import _lib
+    _lib.lib()            # fails loudly if libpq_hip.so is missing
+    assert torch.cuda.is_available()
+    return protoquant_amd
+
+
+def test_golden_quantize(pq, golden):
+    g = golden
+    x = to_gpu(g["x"], g["code"])
+    q = pq.quantize(x, axis=-1)
+    same(q.int_data, g["xq"], "xq"); same(q.scale, g["xs"], "xs")
+    w = to_gpu(g["w"], g["code"])
+    qw = pq.quantize(w, axis=-1)
+    same(qw.int_data, g["wq"], "wq"); same(qw.scale, g["ws"], "ws")
+    qc = pq.quantize(x, axis=0)
+    same(qc.int_data, g["x_colq"], "x_colq"); same(qc.scale, g["x_cols"], "x_cols")
+    same(pq.dequantize(q), g["x_deq"], "x_deq")
+    same(pq.dequantize(qc), g["x_coldeq"], "x_coldeq")
+
+
+@pytest.mark.parametrize("variant", ["auto", "generic", "pp256_16", "pp256_32"])
+def test_golden_gemm_and_qlinear(pq, golden, variant, monkeypatch):
+    g = golden
+    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    xq = torch.from_numpy(g["xq"]).cuda(); wq = torch.from_numpy(g["wq"]).cuda()
+    xs = torch.from_numpy(g["xs"]).cuda(); ws = torch.from_numpy(g["ws"]).cuda()
+    same(pq.int_mm(xq, wq), g["acc"], "acc")
+    bias = to_gpu(g["bias"], g["code"]) if g["bias"] is not None else None
+    same(pq.qlinear_s8(xq, xs, wq, ws, bias, TD[g["code"]]), g["y"], "y")
+
+
+def test_golden_qlinear_module(pq, golden):
+    g = golden
+    lin = torch.nn.Linear(int(g["K"]), int(g["N"]), bias=g["bias"] is not None, device="cuda", dtype=TD[g["code"]])
+    with torch.no_grad():
+        lin.weight.copy_(to_gpu(g["w"], g["code"]))
+        if g["bias"] is not None:
+            lin.bias.copy_(to_gpu(g["bias"], g["code"]))
+    m = pq.qlinear.from_linear(lin)
+    same(m.wq, g["wq"], "module wq"); same(m.ws, g["ws"], "module ws")
+    x = to_gpu(g["x"], g["code"])
+    same(m(x), g["y"], "module y")
+    # [..., K] inputs flatten to [M, K]
+    if x.shape[0] % 2 == 0:
+        y3 = m(x.reshape(2, -1, x.shape[1]))
+        same(y3.reshape(-1, y3.shape[-1]), g["y"], "module y 3-D")
+
+
+SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), (256, 256, 128),
+          (512, 256, 384), (257, 300, 256), (1, 4096, 4096), (333, 1024, 1024), (1024, 768, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("variant", ["auto", "generic", "pp256_16", "pp256_32"])
+def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
+    """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
+    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    rng = np.random.default_rng(M * 1000003 + N * 1009 + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    want = (a.astype(np.int64) @ b.astype(np.int64).T).astype(np.int32)
+    got = pq.int_mm(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    same(got, want, f"acc {M}x{N}x{K} {variant}")
+
+
+@pytest.mark.parametrize("variant", ["pp256_16", "pp256_32", "generic"])
+def test_gemm_identity_asymmetric(pq, variant, monkeypatch):
+    """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
+    monkeypatch.setenv("PQ_FORCE_VARIANT", variant)
+    n = 256
+    a = np.eye(n, dtype=np.int8)
+    b = (np.arange(n * n, dtype=np.int64).reshape(n, n) % 251 - 125).astype(np.int8)
+    got = pq.int_mm(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    same(got, b.T.astype(np.int32), "identity")
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (7, 13), (33, 1000), (64, 4096), (5, 11008), (3, 28672), (2, 40000),
+                                        (129, 520), (0, 16), (4, 0)])
+def test_quant_vs_oracle(pq, code, rows, cols):
+    rng = np.random.default_rng(rows * 7919 + cols + code)
+    xf = (rng.standard_normal((rows, cols)) * rng.uniform(0.01, 30)).astype(np.float32)
+    if rows > 2 and cols > 2:
+        xf[1] = 0
+        xf[2, 0] = 1e30 if code != 1 else 60000
+    x = Q.from_f32(xf, code)
+    xg = to_gpu(x, code)
+    q = pq.quantize(xg, axis=-1)
+    wq, wsc = C.quant_rowwise(x, code)
+    same(q.int_data, wq, "rowwise codes"); same(q.scale, wsc, "rowwise scale")
+    for dt in (0, 1, 2):
+        same(pq.dequantize(q, TD[dt]), C.dequant(wq, wsc, 1, dt), f"dequant->{dt}")
+    if rows > 0 and cols > 0:
+        qc = pq.quantize(xg, axis=0)
+        cq, cs = C.quant_colwise(x, code)
+        same(qc.int_data, cq, "colwise codes"); same(qc.scale, cs, "colwise scale")
+        same(pq.dequantize(qc), C.dequant(cq, cs, 0, code), "col dequant")
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+def test_quant_special_values(pq, code):
+    """NaN / Inf / signalling NaN / subnormal policy (QSPEC Q2, Q5)."""
+    rng = np.random.default_rng(5)
+    xf = rng.standard_normal((9, 64)).astype(np.float32)
+    xf[1, 3] = np.nan; xf[2, 5] = np.inf; xf[3, :] = 0; xf[4, 0] = -np.inf; xf[4, 1] = np.nan
+    xf[5, :] = 1e-41
+    x = Q.from_f32(xf, code)
+    if code != 2:
+        x[6, 2] = 0x7F81 if code == 0 else 0x7C01
+    xg = to_gpu(x, code)
+    q = pq.quantize(xg, axis=-1)
+    wq, wsc = C.quant_rowwise(x, code)
+    same(q.int_data, wq, "codes"); same(q.scale, wsc, "scale")
+    qc = pq.quantize(xg, axis=0)
+    cq, cs = C.quant_colwise(x, code)
+    same(qc.int_data, cq, "col codes"); same(qc.scale, cs, "col scale")
+
+
+def test_quant_strided_and_unaligned(pq):
+    """Leading dimension > cols and an odd element offset take the generic paths."""
+    rng = np.random.default_rng(11)
+    big = torch.from_numpy(rng.standard_normal((40, 1030)).astype(np.float32)).cuda().to(torch.bfloat16)
+    for view in (big[:, :1024], big[:, 1:1025], big[:, 3:1003], big[5:, 8:520]):
+        x = view
+        xb = bits(x.contiguous())
+        q = pq.quantize(x, axis=-1)
+        wq, wsc = C.quant_rowwise(xb, 0)
+        same(q.int_data, wq, "strided codes"); same(q.scale, wsc, "strided scale")
+        qc = pq.quantize(x, axis=0)
+        cq, cs = C.quant_colwise(xb, 0)
+        same(qc.int_data, cq, "strided col codes"); same(qc.scale, cs, "strided col scale")
+
+
+@pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
+                                              (512, 1024, 512, 0, False)])
+@pytest.mark.parametrize("variant", ["auto", "generic", "pp256_32"])
+def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, monkeypatch):
+    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    rng = np.random.default_rng(M + N + K + code)
+    x = Q.from_f32(rng.standard_normal((M, K)).astype(np.float32), code)
+    w = Q.from_f32((rng.standard_normal((N, K)) * 0.02).astype(np.float32), code)
+    b = Q.from_f32((rng.standard_normal(N) * 0.01).astype(np.float32), code) if bias else None
+    wq, ws = C.quant_rowwise(w, code)
+    y_want, xq_want, xs_want, acc_want = Q.qlinear(x, code, wq, ws, b)
+    lin = torch.nn.Linear(K, N, bias=bias, device="cuda", dtype=TD[code])
+    with torch.no_grad():
+        lin.weight.copy_(to_gpu(w, code))
+        if bias:
+            lin.bias.copy_(to_gpu(b, code))
+    m = pq.qlinear.from_linear(lin)
+    same(m(to_gpu(x, code)), y_want, "qlinear y")
+    same(pq.int_mm(torch.from_numpy(xq_want).cuda(), torch.from_numpy(wq).cuda()), acc_want, "acc")
+
+
+def test_full_size_cfg2_properties(pq):
+    """BASELINE config 2 (M=N=K=4096, bf16): size-independent checks + sampled exact parity.
+    (a) xq/xs bit-exact vs the C oracle on all rows; (b) int32 accumulator exact vs int64 matmul on
+    256 sampled rows x all columns; (c) y bit-identical to the oracle epilogue on those rows;
+    (d) linearity of the integer GEMM: acc(a, b1) + acc(a, b2) == acc(a, b1 + b2) for small codes."""
+    M = N = K = 4096
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    xb, wb = bits(x), bits(w)
+    lin = torch.nn.Linear(K, N, bias=False, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(w.cuda())
+    m = pq.qlinear.from_linear(lin)
+    wq, ws = C.quant_rowwise(wb, 0)
+    same(m.wq, wq, "wq 4096"); same(m.ws, ws, "ws 4096")
+    xq_t = pq.quantize(x.cuda())
+    xq, xs = C.quant_rowwise(xb, 0)
+    same(xq_t.int_data, xq, "xq 4096"); same(xq_t.scale, xs, "xs 4096")
+    acc = pq.int_mm(xq_t.int_data, m.wq)
+    y = m(x.cuda())
+    rows = np.random.default_rng(0).choice(M, 256, replace=False)
+    acc_want = (xq[rows].astype(np.int64) @ wq.astype(np.int64).T).astype(np.int32)
+    same(acc[torch.from_numpy(rows).cuda()], acc_want, "acc rows 4096")
+    y_want = Q.epilogue(acc_want, xs[rows], ws, None, 0)
+    same(y[torch.from_numpy(rows).cuda()], y_want, "y rows 4096")
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda")
+    b1 = torch.randint(-60, 60, (N, K), dtype=torch.int8, device="cuda")
+    b2 = torch.randint(-60, 60, (N, K), dtype=torch.int8, device="cuda")
+    lhs = pq.int_mm(a, b1) + pq.int_mm(a, b2)
+    rhs = pq.int_mm(a, (b1 + b2))
+    assert torch.equal(lhs, rhs)
+    # checksum of checksums: column sums of acc == (sum_m a[m,:]) . b^T computed in int64 on the host
+    colsum = acc.sum(dim=0, dtype=torch.int64).cpu().numpy()
+    want = xq.astype(np.int64).sum(axis=0) @ wq.astype(np.int64).T
+    assert np.array_equal(colsum, want)
+
+
+def test_errors_are_loud(pq):
+    from protoquant_amd import _lib
+    with pytest.raises(_lib.PQError):
+        pq.quantize(torch.randn(4, 4))                       # CPU tensor: no fallback
+    with pytest.raises(TypeError):
+        pq.quantize(torch.zeros(4, 4, dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        pq.int_mm(torch.zeros(4, 8, dtype=torch.int8, device="cuda"), torch.zeros(4, 16, dtype=torch.int8, device="cuda"))
+    L = _lib.lib()
+    st = L.pq_quant_rowwise(None, 0, 4, 4, 2, None, 4, None, None)
+    assert st == 1 and b"pq_quant_rowwise" in L.pq_last_error()
