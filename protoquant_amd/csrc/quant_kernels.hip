@@ -28,7 +28,10 @@ template <> struct Unpack<PQ_FP16, 8> {
 template <> struct Unpack<PQ_F32, 4> {
     __device__ static __forceinline__ void run(const v4u& v, float (&f)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t u = v[i];   // copy first: bit_cast of a vector-element lvalue reads element 0
+            f[i] = __builtin_bit_cast(float, u);
+        }
     }
 };
 

@@ -45,7 +45,10 @@ def _as_2d(x: torch.Tensor, axis: int):
         raise ValueError("quantize() needs at least 1 dimension")
     a = axis % nd
     if a == nd - 1:
-        return x.reshape(-1, x.shape[-1]), 1
+        lead = 1
+        for d in x.shape[:-1]:
+            lead *= d
+        return x.reshape(lead, x.shape[-1]), 1
     if nd == 2 and a == 0:
         return x, 0
     raise ValueError("quantize(): axis must be the last axis, or axis 0 of a 2-D tensor")
@@ -73,7 +76,13 @@ def dequantize(q: QTensor, dtype: torch.dtype | None = None) -> torch.Tensor:
     dtype = dtype or q.orig_dtype
     L.require_gpu(q.int_data, "dequantize(q)")
     code = L.dtype_code(dtype)
-    d2 = q.int_data.reshape(-1, q.shape[-1]) if q.axis == 1 else q.int_data
+    if q.axis == 1:
+        lead = 1
+        for d in q.shape[:-1]:
+            lead *= d
+        d2 = q.int_data.reshape(lead, q.shape[-1])
+    else:
+        d2 = q.int_data
     d2 = L.row_major_2d(d2)
     rows, cols = d2.shape
     out = torch.empty((rows, cols), dtype=dtype, device=d2.device)
