@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X dynamic-int8 linear path.
+
+Metric (BASELINE.json): int8 TOPS (+ HBM GB/s of the quant pass) for qlinear M=4096 N=K=4096.
+One *step* = one qlinear forward over one batch of M=4096 synthetic bf16 tokens that is already
+resident in HBM: K1 per-token row-quant (pq_quant_rowwise) -> K3/K4 int8 MFMA GEMM + fused dequant
+epilogue (pq_qlinear_s8), weights pre-quantised per output channel (as a deployed qlinear holds them).
+Both launches go through the C-ABI of libpq_hip.so on torch's current stream, captured in a hipGraph.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): data-parallel over
+tokens — every rank runs the same step on its own 4096-token batch with replicated weights, no
+data-path collective (weak scaling).  `--mode tp` instead column-shards the weight (N/G output
+channels per rank) and all-gathers the transposed output shards with RCCL (BASELINE config 5 layout).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (GEMM kernel vs the
+5.033 POPS dense int8 MFMA peak, timed live with HIP events) and `cpu_baseline` (the QSPEC pipeline
+around torch._int_mm on the host cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_INT8_TOPS = 5033.0     # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (MI355X_MICROARCH.md:28-34,435)
+PEAK_HBM_GBS = 8000.0       # spec; 6290 GB/s measured copy (MI355X_MICROARCH.md:36)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--M", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--mode", choices=["dp", "tp"], default="dp")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def ev_time_us(fn, iters):
+    """Average duration of `fn` (one kernel launch) over `iters` back-to-back launches, HIP events on
+    the launch stream."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        fn()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def cpu_baseline(M, N, K):
+    """'protoquant's own CPU path': QSPEC around torch._int_mm on this box's host cores (oracle/torch_ref.py).
+    Bounded sample: a few repetitions of the same M x N x K qlinear."""
+    from oracle import torch_ref as R
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    wq, ws = R.quantize_ref(w, 1)
+    reps, ts = 6, []
+    R.qlinear_ref(x, wq, ws, None)
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        R.qlinear_ref(x, wq, ws, None)
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 25:
+            break
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(2.0 * M * N * K / med / 1e12, 4), "unit": "TOPS", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{len(ts)} reps of the full {M}x{N}x{K} bf16 qlinear (quant+_int_mm+epilogue), median",
+            "ms_per_step": round(med * 1e3, 2), "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import protoquant_amd as pq
+    from protoquant_amd import _lib as L
+    lib = L.lib()
+
+    M, N, K = args.M, args.N, args.K
+    tp = args.mode == "tp" and world > 1
+    n_local = N // world if tp else N
+    # synthetic data: seeded on the CPU generator so every box agrees; rank offsets the seed
+    g = torch.Generator().manual_seed(1234 + (0 if tp else rank))
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    gw = torch.Generator().manual_seed(4321)
+    w = (torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16)
+    if tp:
+        w = w[rank * n_local:(rank + 1) * n_local]
+    qw = pq.quantize(w.to(dev))                 # one-time weight quantisation (K1 over W's rows)
+    wq, ws = qw.int_data, qw.scale
+    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
+    xs = torch.empty((M,), dtype=torch.float32, device=dev)
+    y = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
+    y_full = torch.empty((world * M * n_local,), dtype=torch.bfloat16, device=dev) if tp else None
+
+    def k1():
+        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "pq_quant_rowwise")
+
+    def k3():
+        L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
+                                  y.data_ptr(), n_local, 0, M, n_local, K, None, 0,
+                                  torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
+
+    def step_eager():
+        k1()
+        k3()
+        if tp:
+            dist.all_gather_into_tensor(y_full, y.view(-1))
+
+    # hipGraph capture of the two launches (the collective, if any, stays outside the graph)
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                k1(); k3()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                k1(); k3()
+        except Exception as e:   # report, never silently change what is measured
+            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
+            graph = None
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            if tp:
+                dist.all_gather_into_tensor(y_full, y.view(-1))
+        else:
+            step_eager()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    dt_ev = e0.elapsed_time(e1) * 1e-3
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel durations, live, HIP events on the launch stream
+    it = max(50, min(args.steps, 500))
+    t_gemm = ev_time_us(k3, it)
+    t_k1 = ev_time_us(k1, it)
+    torch.cuda.synchronize()
+
+    ops_step = 2.0 * M * n_local * K                       # per rank
+    total_ops = ops_step * world * args.steps
+    value = total_ops / dt / 1e12
+    k1_bytes = 3 * M * K + 4 * M                           # read bf16, write s8 + one f32 per row
+    gemm_bytes = M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local)
+
+    out = {
+        "metric": "int8 TOPS, fused qlinear (row-quant + s8 MFMA GEMM + dequant epilogue)",
+        "value": round(value, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+        "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
+                   "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" if tp else f"dp{world} over tokens, replicated int8 weights"),
+                   "launch": "hipgraph" if graph is not None else "eager",
+                   "gemm_variant": lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()},
+        "roofline": {"bound": "mfma", "kernel": "gemm_s8_pp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
+                     "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(2.0 * M * n_local * K / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
+                     "avg_kernel_us": round(t_gemm, 2), "traffic": None,
+                     "algorithmic_bytes": gemm_bytes},
+        "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1),
+                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4),
+                       "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes},
+        "event_ms_per_step": round(dt_ev / args.steps * 1e3, 5),
+    }
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            tr = json.load(open(tj))
+            out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(M, N, K)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
