@@ -203,7 +203,7 @@ def main():
                    "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" if tp else f"dp{world} over tokens, replicated int8 weights"),
                    "launch": "hipgraph" if graph is not None else "eager",
                    "gemm_variant": lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()},
-        "roofline": {"bound": "mfma", "kernel": "gemm_s8_pp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
+        "roofline": {"bound": "mfma", "kernel": "gemm_s8_sp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
                      "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(2.0 * M * n_local * K / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
                      "avg_kernel_us": round(t_gemm, 2), "traffic": None,
                      "algorithmic_bytes": gemm_bytes},

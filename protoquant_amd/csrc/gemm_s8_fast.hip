@@ -4,19 +4,23 @@
 // Structure (designed for CDNA4):
 //   * 256 x 256 output tile per workgroup, K step = 128 bytes, 512 threads = 8 waves = 2 per SIMD.
 //   * MFMA roles: first operand P = weight rows (n), second operand Q = activation rows (m); a lane's
-//     accumulator registers are then consecutive n of ONE output row m -> contiguous y stores.
+//     accumulator registers are then consecutive n of ONE output row m.
 //   * wave (wp, wq) = (w>>2, w&3) owns n-range wp*128+[0,128) x m-range wq*64+[0,64), split in
 //     halves hP (64 n) x hQ (32 m): four quadrants of 16 (16x16x64) or 8 (32x32x32) MFMAs.
 //   * LDS: 2 buffers x {P half0, P half1, Q half0, Q half1} x 16 KiB = 128 KiB, one __shared__
 //     array.  A half-tile is [128 rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
-//     (conflict-free ds_read_b128 for both MFMA shapes).  Staging is global_load_lds_dwordx4: the LDS
-//     image is lane-linear, the XOR goes on the per-lane SOURCE address.
-//   * Ping-pong: waves 0-3 and 4-7 (SIMD partners) run one barrier apart, so on every SIMD one wave
-//     issues MFMAs while its partner issues LDS reads + the next half-tile's DMA.
-//   * One K-tile = 4 phases; phase p stages one half-tile of tile t+1, so every DMA has >= 2 phases
-//     (~1000 cycles) to land.  Waits are counted (vmcnt(4)), never 0 in the loop; barriers are raw
-//     s_barrier.  RAW: a half-tile is read one phase after the vmcnt that retires it (+ barrier).
-//     WAR: a slot is restaged >= 2 phases after its last ds_read.
+//     (measured conflict-free for ds_read_b128 with both MFMA shapes).  Staging is
+//     global_load_lds_dwordx4: the LDS image is lane-linear, the XOR goes on the per-lane SOURCE address.
+//   * ONE s_barrier per K-tile (a barrier round trip costs ~130-150 cycles on this chip, measured; an
+//     8-barrier ping-pong spent 40 % of the loop in them).  Each wave pipelines itself: fragments are
+//     double-buffered in registers and the LDS reads of quadrant q+1 are issued before the MFMAs of
+//     quadrant q.  The barrier sits mid-tile (between quadrants 1 and 2): by then every wave has
+//     issued+retired its last read of tile t (so tile t's buffer can be refilled with tile t+2) and
+//     has waited for its own DMA pieces of tile t+1 (so tile t+1 is visible to all after the barrier).
+//     Every DMA therefore has a whole K-tile of MFMA time (~2000 cycles) to land.
+//   * Epilogue: scales applied in registers, tile transposed through LDS (per-wave private region),
+//     written with 16-byte stores as 256-byte row segments.
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_epilogue.h"
@@ -27,7 +31,9 @@ constexpr int FT = 256;          // tile edge (both m and n)
 constexpr int FBK = 128;         // K bytes per tile step
 constexpr int HALF_BYTES = 128 * FBK;        // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;    // 64 KiB
-constexpr int LDS_BYTES = 2 * BUF_BYTES;     // 128 KiB
+constexpr int EPI_ROW = 256 + 16;            // epilogue staging row: 256 B payload + 16 B pad
+constexpr int EPI_WAVE = 64 * EPI_ROW;       // 17 KiB per wave
+constexpr int LDS_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -36,18 +42,28 @@ __device__ __forceinline__ void glds16(const int8_t* g, uint8_t* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-#define PQ_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
 // XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int OUT, int SHAPE>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32
-__global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict__ X, int64_t ldx,
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+template <int OUT, int SHAPE, int ABL>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
+__global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
-                                                        int M, int N, int K, int tiles_m, int tiles_n) {
+                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg) {
+    // ablation bits (dev builds only): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue, 16 direct epilogue
+    constexpr bool DBG = ABL != 0;
+    constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
+    (void)dbg;
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,14 +96,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict
             offP[h][jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
             offQ[h][jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
         }
-    const int8_t* gP = W + (int64_t)n0 * ldw;   // uniform; advanced by FBK per K-tile
+    const int8_t* gP = W + (int64_t)n0 * ldw;   // uniform; advanced by FBK per staged K-tile
     const int8_t* gQ = X + (int64_t)m0 * ldx;
+    const int piece_off = w * 2048;             // pieces w*2 and w*2+1 of a half-tile
 
-    // LDS destinations (wave-uniform): half-tile base + piece*1024
-    auto lds_half = [&](int buf, int isQ, int h) -> uint8_t* { return smem + buf * BUF_BYTES + isQ * 2 * HALF_BYTES + h * HALF_BYTES; };
-    const int piece_off = w * 2048;   // pieces w*2 and w*2+1
-
-    // ---- fragment read addresses (lane part), ks selects the 64-byte half of the 128-byte row
+    // ---- fragment read addresses (lane part)
     constexpr int NPI = (SHAPE == 16) ? 4 : 2;     // P tiles per half (64 rows)
     constexpr int NQJ = (SHAPE == 16) ? 2 : 1;     // Q tiles per half (32 rows)
     constexpr int NKS = (SHAPE == 16) ? 2 : 4;     // MFMA k-steps per 128-byte row
@@ -95,7 +108,6 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict
     const int frow = (SHAPE == 16) ? (lane & 15) : (lane & 31);
     const int fchunk = (SHAPE == 16) ? (lane >> 4) : (lane >> 5);
     const int fkey = (frow >> 1) & 7;
-    // byte address of (row frow + rowbase, logical chunk c) = row*128 + ((c ^ key) * 16); c = ks*(8/NKS) + fchunk
     uint32_t lP[NKS], lQ[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -117,100 +129,203 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict
 #pragma unroll
                     for (int r = 0; r < NACC; ++r) acc[a][b][i][j][r] = 0;
 
-    v4i fP[NPI][NKS], fQ0[NQJ][NKS], fQ1[NQJ][NKS];
-
-    auto stage = [&](int buf, int isQ, int h) {   // 2 x global_load_lds_dwordx4 per wave
-        uint8_t* l = lds_half(buf, isQ, h) + piece_off;
-        const int8_t* g = isQ ? gQ : gP;
-        const uint32_t o0 = isQ ? offQ[h][0] : offP[h][0], o1 = isQ ? offQ[h][1] : offP[h][1];
-        glds16(g + o0, l);
-        glds16(g + o1, l + 1024);
-    };
-    auto readP = [&](int bufoff, int h) {
+    v4i fPa[NPI][NKS], fPb[NPI][NKS], fQa[NQJ][NKS], fQb[NQJ][NKS];
+    if constexpr (DBG) {   // defined operands when LDS reads are ablated
 #pragma unroll
         for (int i = 0; i < NPI; ++i)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                fP[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * HALF_BYTES + i * SHAPE * 128);
-    };
-    auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) {
+            for (int ks = 0; ks < NKS; ++ks) { fPa[i][ks] = v4i{lane, i, ks, 1}; fPb[i][ks] = v4i{lane, i, ks, 4}; }
 #pragma unroll
         for (int j = 0; j < NQJ; ++j)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * HALF_BYTES + j * SHAPE * 128);
+            for (int ks = 0; ks < NKS; ++ks) { fQa[j][ks] = v4i{lane, j, ks, 2}; fQb[j][ks] = v4i{lane, j, ks, 3}; }
+    }
+
+    // ---- issue items.  Everything below is hand-interleaved: ONE item in the shadow of each MFMA.
+    // DMA piece g (0..7) of a K-tile, in need order P0a P0b Q0a Q0b Q1a Q1b P1a P1b
+    auto dma_item = [&](int buf, auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int isQ = (g >= 2 && g < 6), h = (g >= 4), jj = g & 1;
+        if (!no_dma) {
+            uint8_t* l = smem + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
+            glds16(isQ ? gQ + offQ[h][jj] : gP + offP[h][jj], l);
+        }
+        if constexpr (g == 7) { gP += FBK; gQ += FBK; }
     };
-    auto mma = [&](acc_t (&c)[NPI][NQJ], v4i (&fq)[NQJ][NKS]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int i = 0; i < NPI; ++i)
-#pragma unroll
-                for (int j = 0; j < NQJ; ++j) {
-                    if constexpr (SHAPE == 16) c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fP[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
-                    else c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fP[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
+    auto stage_tile = [&](int buf) {   // whole tile at once (prologue only)
+        static_for<8>([&](auto gc) { dma_item(buf, gc); });
+    };
+    // fragment item it: P: i = it % NPI, ks = it / NPI (8 items); Q: j = it % NQJ, ks = it / NQJ (4 items)
+    auto readP_item = [&](int bufoff, int h, v4i (&f)[NPI][NKS], auto ic) {
+        constexpr int it = decltype(ic)::value, i = it % NPI, ks = it / NPI;
+        if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * HALF_BYTES + i * SHAPE * 128);
+    };
+    auto readQ_item = [&](int bufoff, int h, v4i (&f)[NQJ][NKS], auto ic) {
+        constexpr int it = decltype(ic)::value, j = it % NQJ, ks = it / NQJ;
+        if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * HALF_BYTES + j * SHAPE * 128);
+    };
+    auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<8>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
+    auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) { static_for<4>([&](auto ic) { readQ_item(bufoff, h, f, ic); }); };
+
+    constexpr int NM = NKS * NPI * NQJ;          // MFMAs per quadrant: 16 or 8
+    constexpr int PPS = 8 / (NM / 2);            // P reads (or DMA pieces) per slot: 1 or 2
+    // One quadrant: MFMA idx, then slot(idx) in its shadow.  The first MFMA needs this quadrant's own
+    // operands (all issued during the previous quadrant) -> hipcc's wait there is an exact lgkmcnt(0).
+    auto mma = [&](acc_t (&c)[NPI][NQJ], v4i (&fp)[NPI][NKS], v4i (&fq)[NQJ][NKS], auto&& slot) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NM>([&](auto xc) {
+            constexpr int x = decltype(xc)::value, ks = x / (NPI * NQJ), i = (x / NQJ) % NPI, j = x % NQJ;
+            if (!no_mma) {
+                if constexpr (SHAPE == 16) c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
+                else c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            slot(xc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     const int NT = K / FBK;
 
-    // ---- prologue: all of tile 0, in need order P0, Q0, Q1, P1
-    stage(0, 0, 0); stage(0, 1, 0); stage(0, 1, 1); stage(0, 0, 1);
-    gP += FBK; gQ += FBK;
-    PQ_WAIT_VMCNT(4);                       // P0, Q0 landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-    if (wp == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one barrier behind
+    // One K-tile, branch-free inside (flags are compile-time).  Quadrant order (P0,Q0) (P0,Q1) (P1,Q0)
+    // (P1,Q1): every register set returns to the same role each tile.  Entry: fPa = P0[kt], fQa = Q0[kt].
+    //   q0: MFMA acc[0][0] (fPa, fQa)   | slots: read Q1[kt] -> fQb
+    //   q1: MFMA acc[0][1] (fPa, fQb)   | slots: read P1[kt] -> fPb            <- last LDS read of tile kt
+    //   --- vmcnt(0) + lgkmcnt(0) + s_barrier: tile kt+1 visible to all, tile kt's buffer free ---
+    //   q2: MFMA acc[1][0] (fPb, fQa)   | slots: read P0[kt+1] -> fPa, then DMA tile kt+2
+    //   q3: MFMA acc[1][1] (fPb, fQb)   | slots: read Q0[kt+1] -> fQa (free after q2)
+    auto tile = [&](int kt, auto has_next, auto has_next2) {
+        const int bufoff = (kt & 1) * BUF_BYTES;
+        constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value;
+        mma(acc[0][0], fPa, fQa, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (x < 4) readQ_item(bufoff, 1, fQb, xc);
+        });
+        mma(acc[0][1], fPa, fQb, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+        });
+        if constexpr (next) {
+            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
+            __builtin_amdgcn_s_barrier();
+        }
+        mma(acc[1][0], fPb, fQa, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+            if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
+        });
+        mma(acc[1][1], fPb, fQb, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
+        });
+    };
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
 
-    int bufoff = 0;
-    for (int kt = 0; kt < NT; ++kt) {
-        const bool more = (kt + 1 < NT);
-        const int nb = (kt + 1) & 1;
-        // -------- phase 0: quadrant (hP0, hQ0)
-        readQ(bufoff, 0, fQ0);
-        __builtin_amdgcn_sched_barrier(0);
-        readP(bufoff, 0);
-        if (more) { stage(nb, 0, 0); PQ_WAIT_VMCNT(4); } else { PQ_WAIT_VMCNT(2); }   // Q1(t) landed
-        __builtin_amdgcn_s_barrier();
-        mma(acc[0][0], fQ0);
-        __builtin_amdgcn_s_barrier();
-        // -------- phase 1: quadrant (hP0, hQ1)
-        readQ(bufoff, 1, fQ1);
-        if (more) { stage(nb, 1, 0); PQ_WAIT_VMCNT(4); } else { PQ_WAIT_VMCNT(0); }   // P1(t) landed
-        __builtin_amdgcn_s_barrier();
-        mma(acc[0][1], fQ1);
-        __builtin_amdgcn_s_barrier();
-        // -------- phase 2: quadrant (hP1, hQ1)
-        readP(bufoff, 1);
-        if (more) { stage(nb, 1, 1); }
-        __builtin_amdgcn_s_barrier();
-        mma(acc[1][1], fQ1);
-        __builtin_amdgcn_s_barrier();
-        // -------- phase 3: quadrant (hP1, hQ0) — Q0 fragments kept in registers
-        if (more) { stage(nb, 0, 1); PQ_WAIT_VMCNT(4); }                                // P0, Q0 (t+1) landed
-        __builtin_amdgcn_s_barrier();
-        mma(acc[1][0], fQ0);
-        __builtin_amdgcn_s_barrier();
-        gP += FBK; gQ += FBK;
-        bufoff ^= BUF_BYTES;
-    }
-    if (wp == 0) __builtin_amdgcn_s_barrier();   // matches the stagger barrier of waves 4-7
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, first fragments in registers
+    stage_tile(0);
+    if (NT > 1) { stage_tile(1); __builtin_amdgcn_s_waitcnt(0x0078); }   // vmcnt(8) lgkmcnt(0)
+    else { __builtin_amdgcn_s_waitcnt(0x0070); }                          // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    readP(0, 0, fPa);
+    readQ(0, 0, fQa);
+
+    int kt = 0;
+    for (; kt + 2 < NT; ++kt) tile(kt, yes, yes);
+    if (kt + 1 < NT) { tile(kt, yes, no); ++kt; }
+    tile(kt, no, no);
 
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
+    if (no_epi) {   // keep the accumulators live, write (almost) nothing
+        int sink = 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NQJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < NACC; ++r) sink ^= acc[a][b][i][j][r];
+        if (sink == 0x12345678) reinterpret_cast<int*>(epi.y)[tid] = sink;
+        return;
+    }
+
     using O = typename OutElem<OUT>::type;
+    constexpr int OB = (int)sizeof(O);
     O* y = reinterpret_cast<O*>(epi.y);
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(O) - 1)) == 0) && ((epi.ldy & 3) == 0);
-    // column (m) index of this lane inside a Q tile, row (n) group inside a P tile
-    const int dcol = (SHAPE == 16) ? (lane & 15) : (lane & 31);
-    const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // + 8*g for 32x32 groups
-    constexpr int NG = (SHAPE == 16) ? 1 : 4;      // groups of 4 consecutive n per tile register file
+    const int dcol = (SHAPE == 16) ? (lane & 15) : (lane & 31);            // m inside a Q tile
+    const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // first of 4 consecutive n (+8g for 32x32)
+    constexpr int NG = (SHAPE == 16) ? 1 : 4;
+    const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 128;                      // this wave's 64(m) x 128(n) block
+
+    // staged path: whole block in range, 16-byte aligned rows
+    const bool staged = !direct_epi && (wm0 + 64 <= M) && (wn0 + 128 <= N) &&
+                        ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
+    __builtin_amdgcn_s_barrier();     // every wave is done reading the K-loop buffers (uniform: all waves reach it)
+    if (staged) {
+        uint8_t* sw = smem + w * EPI_WAVE;
+        constexpr int NPASS = (OB == 2) ? 1 : 2;          // 256-byte rows: 128 n of 2 bytes, or 64 n of 4 bytes
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int hQ = 0; hQ < 2; ++hQ)
+#pragma unroll
+                for (int j = 0; j < NQJ; ++j) {
+                    const int ml = hQ * 32 + j * SHAPE + dcol;
+                    float as = 1.0f;
+                    if constexpr (OUT != OUT_I32) as = epi.a_scale[wm0 + ml];
+#pragma unroll
+                    for (int hP = 0; hP < 2; ++hP) {
+                        if (NPASS == 2 && hP != pass) continue;
+#pragma unroll
+                        for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const int nl = hP * 64 + i * SHAPE + drow4 + 8 * g;       // inside the wave block
+                                const acc_t& c = acc[hP][hQ][i][j];
+                                v4f bs = {1.f, 1.f, 1.f, 1.f};
+                                float bf[4] = {0.f, 0.f, 0.f, 0.f};
+                                if constexpr (OUT != OUT_I32) {
+                                    bs = *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + nl);
+                                    if (has_bias) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
+                                    }
+                                }
+                                O o[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs[r], bf[r], has_bias);
+                                const int ncol = (NPASS == 2) ? (nl - pass * 64) : nl;
+                                uint8_t* d = sw + ml * EPI_ROW + ncol * OB;
+                                if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
+                                else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
+                            }
+                    }
+                }
+            // wave-private region: only this wave's LDS writes must retire before its reads (no barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + (lane >> 4), ch = lane & 15;
+                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ch * 16);
+                uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
+                *reinterpret_cast<v4u*>(dst) = v;
+            }
+            if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before pass 1 overwrites
+        }
+        return;
+    }
+
+    // direct path (edge tiles / unaligned y): guarded stores straight from registers
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
 #pragma unroll
     for (int hQ = 0; hQ < 2; ++hQ)
 #pragma unroll
         for (int j = 0; j < NQJ; ++j) {
-            const int m = m0 + wq * 64 + hQ * 32 + j * SHAPE + dcol;
+            const int m = wm0 + hQ * 32 + j * SHAPE + dcol;
             const bool mok = m < M;
             float as = 1.0f;
             if constexpr (OUT != OUT_I32) as = mok ? epi.a_scale[m] : 0.0f;
@@ -220,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict
                 for (int i = 0; i < NPI; ++i)
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        const int n = n0 + wp * 128 + hP * 64 + i * SHAPE + drow4 + 8 * g;
+                        const int n = wn0 + hP * 64 + i * SHAPE + drow4 + 8 * g;
                         if (!mok || n >= N) continue;
                         const acc_t& c = acc[hP][hQ][i][j];
                         O* dst = y + (int64_t)m * epi.ldy + n;
@@ -235,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_pp256(const int8_t* __restrict
                                 }
                                 o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias);
                             }
-                            if constexpr (sizeof(O) == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+                            if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
                             else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
                         } else {
 #pragma unroll
@@ -259,12 +374,24 @@ bool gemm_fast_eligible(const int8_t* A, int64_t lda, const int8_t* B, int64_t l
            M < (1 << 30) && N < (1 << 30) && lda < (1 << 23) && ldb < (1 << 23);
 }
 
+int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
+
 template <int OUT, int SHAPE>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
                       int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + FT - 1) / FT), tiles_n = (int)((N + FT - 1) / FT);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
-    gemm_s8_pp256<OUT, SHAPE><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+#ifdef PQ_ABLATION_BUILD
+    if constexpr (OUT == PQ_BF16 && SHAPE == 16) {
+        switch (gemm_debug_flags()) {
+#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n); return;
+            PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16)
+#undef PQ_ABL
+            default: break;
+        }
+    }
+#endif
+    gemm_s8_sp256<OUT, SHAPE, 0><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0);
 }
 
 #define PQ_INST(OUT, SHAPE) \

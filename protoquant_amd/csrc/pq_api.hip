@@ -34,14 +34,14 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_PP256_16, V_PP256_32 };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32 };
 
 Variant forced_variant() {
     const char* e = getenv("PQ_FORCE_VARIANT");
     if (!e || !*e) return V_AUTO;
     if (!strcmp(e, "generic")) return V_GENERIC;
-    if (!strcmp(e, "pp256_16")) return V_PP256_16;
-    if (!strcmp(e, "pp256_32")) return V_PP256_32;
+    if (!strcmp(e, "sp256_16")) return V_SP256_16;
+    if (!strcmp(e, "sp256_32")) return V_SP256_32;
     return V_AUTO;
 }
 
@@ -51,14 +51,14 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     if (f == V_GENERIC || !ok) return V_GENERIC;
     if (f != V_AUTO) return f;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
-    return V_PP256_16;
+    return V_SP256_16;
 }
 
 template <int OUT>
 void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
               int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    if (v == V_PP256_16) pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
-    else if (v == V_PP256_32) {
+    if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_SP256_32) {
         if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32>(a, lda, b, ldb, epi, M, N, K, st);
         else pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
     } else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
@@ -156,8 +156,8 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     // alignment of the pointers is unknown here: assume 16-byte aligned bases
     switch (pick_variant(reinterpret_cast<const int8_t*>(16), lda, reinterpret_cast<const int8_t*>(16), ldb, M, N, K)) {
-        case V_PP256_16: return "pp256_16x16x64";
-        case V_PP256_32: return "pp256_32x32x32";
+        case V_SP256_16: return "sp256_16x16x64";
+        case V_SP256_32: return "sp256_32x32x32";
         default: return "generic64";
     }
 }

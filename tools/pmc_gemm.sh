@@ -1,0 +1,32 @@
+#!/bin/bash
+# Dev tool (GPU box): PMC counter passes for the GEMM kernel. Usage: tools/pmc_gemm.sh <outdir> [extra bench args]
+# Counters are collected in their own runs (no other trace domains), one pass per group.
+set -u
+OUT=$1; shift
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+run() { # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $R/$OUT/$name.log 2>&1
+}
+mkdir -p $R/$OUT
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+run sq2 SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_LDS_UNALIGNED_STALL
+run grbm GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum
+python3 - "$R/$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/*/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0][:60]
+        agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in agg.items():
+    if "at::native" in k: continue
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
+PY

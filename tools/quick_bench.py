@@ -45,7 +45,7 @@ def main():
     os.environ["PQ_FORCE_VARIANT"] = "generic"
     ref_acc = pq.int_mm(qx.int_data, qw.int_data)
     ref_y = pq.qlinear_s8(qx.int_data, qx.scale, qw.int_data, qw.scale, None, torch.bfloat16)
-    for v in ("generic", "pp256_16", "pp256_32"):
+    for v in ("generic", "sp256_16", "sp256_32"):
         os.environ["PQ_FORCE_VARIANT"] = v
         acc = pq.int_mm(qx.int_data, qw.int_data)
         y = pq.qlinear_s8(qx.int_data, qx.scale, qw.int_data, qw.scale, None, torch.bfloat16)
