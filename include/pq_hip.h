@@ -78,6 +78,12 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       void* workspace, size_t workspace_bytes, void* stream);
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+/* Self-test hook: for n (x, s) fp32 bit-pattern pairs, counts in mismatches[0] the pairs whose division-free
+ * code (K1/K2 hot path) differs from clamp(rne(x / s)) and in mismatches[1] the pairs whose rebuilt quotient
+ * differs from the IEEE quotient.  mismatches[2] must be zeroed by the caller.  QSPEC Q4. */
+int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits, int64_t n,
+                                  unsigned long long* mismatches, void* stream);
+
 /* Name of the GEMM kernel variant the dispatcher would pick for this problem (static string). */
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 

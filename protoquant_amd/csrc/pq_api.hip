@@ -14,6 +14,7 @@ template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, i
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
+void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
 namespace {
@@ -151,6 +152,12 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
         default: run_gemm<PQ_F32>(v, a, lda, b, ldb, epi, M, N, K, st); break;
     }
     return check_launch("pq_qlinear_s8");
+}
+
+int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits, int64_t n, unsigned long long* mismatches, void* stream) {
+    if (!x_bits || !s_bits || !mismatches || n < 0) return fail(PQ_ERR_BAD_ARG, "pq_selftest_fast_quotient: bad arguments");
+    pq::launch_fast_quotient_check(x_bits, s_bits, n, mismatches, static_cast<hipStream_t>(stream));
+    return check_launch("pq_selftest_fast_quotient");
 }
 
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {

@@ -36,9 +36,84 @@ template <> struct Unpack<PQ_F32, 4> {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Exact-result fast encode (QSPEC Q4-Q6 without a division per element).
+//   r = RN(1/s): ONE IEEE division per scale.  Per element the correctly rounded quotient Q = RN(x/s) is
+//   rebuilt with two FMA residual corrections (Markstein: with y = RN(1/b) and q within 1 ulp of a/b,
+//   r = a - b*q is exact and RN(q + r*y) = RN(a/b), unless b's significand is all ones):
+//       q = x*r;  e = fma(-q, s, x);  q = fma(e, r, q);  e = fma(-q, s, x);  q = fma(e, r, q)   ==  x / s
+//   then m = q + 1.5*2^23 rounds q to the nearest-even integer k (= rintf) and leaves k's two's complement
+//   in the low mantissa bits, so the code byte is the low byte of m.  |x| <= amax gives |k| <= 127: no clamp.
+// Valid when 2^-60 < s < 2^60, s's significand is not all ones and the data hold no NaN/Inf
+// (scale_fast_ok + the amax bit test); everything else takes the exact-division path.  The identity is
+// checked by brute force on the GPU in tests/test_gpu_parity.py::test_fast_quotient_bruteforce.
+constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23
+
+__device__ __forceinline__ bool scale_fast_ok(float s) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, s);
+    const uint32_t e = b >> 23;                 // s > 0
+    return e >= 67u && e <= 187u && (b & 0x7FFFFFu) != 0x7FFFFFu;
+}
+__device__ __forceinline__ float quotient_fast(float x, float s, float r) {
+    float q = x * r;
+    float e = __builtin_fmaf(-q, s, x);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-q, s, x);
+    q = __builtin_fmaf(e, r, q);
+    return q;
+}
+// encodes N elements; returns the N code bytes packed little-endian
+template <int N>
+__device__ __forceinline__ void fast_encode(const float (&f)[N], float s, float r, uint32_t (&packed)[N / 4]) {
+    uint32_t mb[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) mb[j] = __builtin_bit_cast(uint32_t, quotient_fast(f[j], s, r) + kMagic);
+#pragma unroll
+    for (int g = 0; g < N / 4; ++g)
+        packed[g] = __builtin_amdgcn_perm(mb[4 * g + 1], mb[4 * g], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * g + 3], mb[4 * g + 2], 0x04000c0cu);
+}
+
+// amax of one 16-byte vector on the raw bit patterns (integer max; NaN patterns sort above Inf and are
+// detected afterwards).  Returns max |x| bits widened to f32 bit patterns.
+template <int DT>
+__device__ __forceinline__ uint32_t vec_amax_bits(const v4u& v, uint32_t cur) {
+    if constexpr (DT == PQ_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t a = v[i] & 0x7FFFFFFFu; cur = a > cur ? a : cur; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = v[i] & 0x7FFF7FFFu;
+            const uint32_t lo = a & 0xFFFFu, hi = a >> 16;
+            const uint32_t mx = lo > hi ? lo : hi;
+            cur = mx > cur ? mx : cur;
+        }
+    }
+    return cur;
+}
+template <int DT> __device__ __forceinline__ bool amax_bits_has_nan(uint32_t b) {
+    if constexpr (DT == PQ_F32) return b > 0x7F800000u;
+    else if constexpr (DT == PQ_BF16) return b > 0x7F80u;
+    else return b > 0x7C00u;
+}
+template <int DT> __device__ __forceinline__ float amax_bits_to_f32(uint32_t b) {
+    if constexpr (DT == PQ_F32) return __builtin_bit_cast(float, b);
+    else return Elem<DT>::to_f32((uint16_t)b);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1 vector path.  TPR threads own one row; thread t holds 16-byte vectors t, t+TPR, ... (VPT of
-// them) so every wave-instruction reads 1 KiB contiguous.  Algorithmic traffic: read once, write
-// 1 B/elem + 4 B/row.
+// them) so every wave-instruction reads 1 KiB contiguous.  A row group (wave for TPR=64, block for
+// TPR=256) walks rows g, g+G, g+2G, ... two at a time with both rows' loads issued up front, so one
+// row's HBM latency hides under the other's arithmetic and stores.  Algorithmic traffic: read once,
+// write 1 B/elem + 4 B/row.
 template <int DT, int VPT, int TPR>
 __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restrict__ x, int64_t rows, int nvec,
                                                          int64_t ldx_bytes, int8_t* __restrict__ q, int64_t ldq,
@@ -46,53 +121,111 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     constexpr int RPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
-    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
-    const bool active = row < rows;
-    const uint8_t* xr = x + (active ? row : 0) * ldx_bytes;
+    int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const bool active = row < rows;                 // only the last block can hold inactive row groups (TPR = 64)
+    row = active ? row : rows - 1;
+    const uint8_t* xr = x + row * ldx_bytes;
 
+    // Loads are UNCONDITIONAL (clamped address): a per-element "load or zero" select makes hipcc branch
+    // around every load and wait vmcnt(0) each time.  Duplicates of the clamped tail vector do not change a max.
     v4u v[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int idx = i * TPR + t;
-        v[i] = (active && idx < nvec) ? *reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16) : v4u{0, 0, 0, 0};
+        v[i] = *reinterpret_cast<const v4u*>(xr + (int64_t)(idx < nvec ? idx : nvec - 1) * 16);
     }
-    float amax = 0.0f;
+    // ---- amax (Q2) on bit patterns
+    uint32_t ab = 0;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        float f[EPV];
-        Unpack<DT, EPV>::run(v[i], f);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
-    }
-    amax = wave_max(amax);
+    for (int i = 0; i < VPT; ++i) ab = vec_amax_bits<DT>(v[i], ab);
+    ab = wave_max_u32(ab);
+    __shared__ uint32_t part[256 / kWave];
     if constexpr (TPR > kWave) {
-        __shared__ float part[256 / kWave];
-        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = amax;
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < 256 / kWave; ++w) amax = part[w] > amax ? part[w] : amax;
+        for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
+    }
+    const bool has_nan = amax_bits_has_nan<DT>(ab);
+    float amax = amax_bits_to_f32<DT>(ab);
+    if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare, row re-read from L2
+        amax = 0.0f;
+#pragma unroll 1
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            if (idx < nvec) {
+                float f[EPV];
+                Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
+            }
+        }
+        amax = wave_max(amax);
+        if constexpr (TPR > kWave) {
+            __syncthreads();
+            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
+        }
     }
     const float s = scale_of(amax);
-    if (active && t == 0) scale[row] = s;
     if (!active) return;
+    if (t == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
+    auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
+        if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
+        else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
+    };
+    if (!has_nan && scale_fast_ok(s)) {       // the hot path: no division per element, results identical to x / s
+        const float r = 1.0f / s;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int idx = i * TPR + t;
-        if (idx < nvec) {
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
             float f[EPV];
             Unpack<DT, EPV>::run(v[i], f);
-            int c[EPV];
+            uint32_t pk[EPV / 4];
+            fast_encode<EPV>(f, s, r, pk);
+            if (idx < nvec) store_vec(idx, pk);
+        }
+    } else {                                  // uniform per row group: true division (NaN/Inf data, extreme scales)
+#pragma unroll 1
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            if (idx < nvec) {
+                float f[EPV];
+                Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+                uint32_t pk[EPV / 4];
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) c[j] = code_of(f[j], s);
-            if constexpr (EPV == 8) {
-                v2u o = {pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])};
-                *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = o;
-            } else {
-                *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pack4(c[0], c[1], c[2], c[3]);
+                for (int g = 0; g < EPV / 4; ++g)
+                    pk[g] = pack4(code_of(f[4 * g], s), code_of(f[4 * g + 1], s), code_of(f[4 * g + 2], s), code_of(f[4 * g + 3], s));
+                store_vec(idx, pk);
             }
         }
     }
+}
+
+// dev/test kernel: compares the fast quotient + magic rounding against rintf(x / s) on raw bit patterns.
+// out[0] += number of (x, s) pairs, among the n tested per thread, whose codes differ.
+__global__ void fast_quotient_check(const uint32_t* __restrict__ xbits, const uint32_t* __restrict__ sbits, int64_t n,
+                                    unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = __builtin_bit_cast(float, sbits[i]);
+    float x = __builtin_bit_cast(float, xbits[i]);
+    if (!(s > 0.0f) || !scale_fast_ok(s) || x != x) return;
+    const float lim = 127.0f * s;                      // QSPEC guarantees |x| <= amax = about 127*s
+    x = x > lim ? lim : (x < -lim ? -lim : x);
+    const float r = 1.0f / s;
+    const uint32_t fast = __builtin_bit_cast(uint32_t, quotient_fast(x, s, r) + kMagic) & 0xFFu;
+    const uint32_t want = (uint32_t)code_of(x, s) & 0xFFu;
+    const bool qdiff = __builtin_bit_cast(uint32_t, quotient_fast(x, s, r)) != __builtin_bit_cast(uint32_t, x / s) &&
+                       __builtin_fabsf(x / s) >= 0x1p-40f;
+    if (fast != want) atomicAdd(&out[0], 1ull);
+    if (qdiff) atomicAdd(&out[1], 1ull);
+}
+void launch_fast_quotient_check(const uint32_t* xb, const uint32_t* sb, int64_t n, unsigned long long* out, hipStream_t st) {
+    fast_quotient_check<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(xb, sb, n, out);
 }
 
 // K1 generic path: any cols / leading dimension / alignment.  One block per row, two passes over the

@@ -209,6 +209,31 @@ def test_full_size_cfg2_properties(pq):
     assert np.array_equal(colsum, want)
 
 
+def test_fast_quotient_bruteforce(pq):
+    """The division-free quotient of K1 (two FMA residual corrections on r = RN(1/s)) equals the IEEE quotient,
+    hence the same int8 code, on 2^28 random (x, s) bit patterns: uniform bits, bf16-like x (the tie-heavy
+    case), and scales near powers of two."""
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    n = 1 << 26
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(99)
+    for mode in range(4):
+        xb = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+        sb = torch.randint(0, (1 << 31) - 1, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+        if mode == 1:
+            xb = xb & ~0xFFFF                                # bf16-representable x: exact ties are frequent
+        if mode == 2:
+            sb = (sb & 0x7F800000) | (sb & 0x7)              # scales a few ulps above a power of two
+        if mode == 3:
+            sb = (sb & 0x7F800000) | 0x7FFFF8 | (sb & 0x7)   # scales just below a power of two (incl. all-ones)
+            xb = xb & ~0xFFFF
+        _lib.check(L.pq_selftest_fast_quotient(xb.data_ptr(), sb.data_ptr(), n, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    assert out.tolist() == [0, 0], f"fast quotient mismatches (codes, quotients): {out.tolist()}"
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
