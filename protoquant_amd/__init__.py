@@ -3,5 +3,7 @@
 libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eager fallback."""
 from .qtensor import QTensor, quantize, dequantize
 from .qlinear import qlinear, qlinear_s8, int_mm, swap_linears
+from .sharded import ColumnShardedQLinear, gather_columns, shard_bounds
 
-__all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "int_mm", "swap_linears"]
+__all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "int_mm", "swap_linears",
+           "ColumnShardedQLinear", "gather_columns", "shard_bounds"]

@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the N>1 host logic (shard bounds, the one collective, the layout fix).
+No HIP calls: shards are synthetic tensors whose value encodes (row, global column)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, M, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from protoquant_amd.sharded import gather_columns, shard_bounds
+        lo, hi = shard_bounds(n_total, world, rank)
+        rows = torch.arange(M, dtype=torch.float32)[:, None]
+        cols = torch.arange(lo, hi, dtype=torch.float32)[None, :]
+        y_local = (rows * 10000 + cols).to(torch.bfloat16 if n_total < 200 else torch.float32)
+        y = gather_columns(y_local, n_total)
+        want = (rows * 10000 + torch.arange(n_total, dtype=torch.float32)[None, :]).to(y_local.dtype)
+        ok = y.shape == (M, n_total) and torch.equal(y, want)
+        st = gather_columns(y_local, n_total, stacked=True)
+        ok = ok and st.shape[0] == world and torch.equal(st[rank, :, : hi - lo], y_local)
+        # weak-scaling bench reduction: max over ranks of a per-rank time
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and float(t) == float(world)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,M", [(8, 4), (7, 3), (4096, 16)])
+def test_gather_columns_world2(n_total, M):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n_total, M, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_bounds_cover_exactly():
+    from protoquant_amd.sharded import shard_bounds
+    for n in (1, 7, 8, 4096, 128256, 28672):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(8, 2, 2)

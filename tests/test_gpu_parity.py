@@ -234,6 +234,58 @@ def test_fast_quotient_bruteforce(pq):
     assert out.tolist() == [0, 0], f"fast quotient mismatches (codes, quotients): {out.tolist()}"
 
 
+def test_column_sharded_world1_matches_unsharded(pq):
+    """ColumnShardedQLinear over RCCL (backend nccl) with a 1-rank group == plain qlinear, bit for bit."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(512, 768, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(6, 50, 512, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        y1 = pq.ColumnShardedQLinear.from_linear(lin)(x)
+        assert y1.shape == y0.shape and torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_swap_linears_on_mlp(pq):
+    """Llama-style MLP block (gate/up/down) with every nn.Linear swapped: each projection bit-exact vs the oracle."""
+    torch.manual_seed(5)
+    H, I, M = 256, 640, 96
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate, self.up, self.down = (torch.nn.Linear(H, I, bias=False), torch.nn.Linear(H, I, bias=False),
+                                             torch.nn.Linear(I, H, bias=False))
+
+        def forward(self, x):
+            return self.down(torch.nn.functional.silu(self.gate(x)) * self.up(x))
+
+    mlp = MLP().to("cuda", torch.bfloat16)
+    ws = {n: bits(getattr(mlp, n).weight.detach()) for n in ("gate", "up", "down")}
+    pq.swap_linears(mlp)
+    assert all(isinstance(getattr(mlp, n), pq.qlinear) for n in ("gate", "up", "down"))
+    x = torch.randn(M, H, device="cuda", dtype=torch.bfloat16)
+    g = mlp.gate(x); u = mlp.up(x)
+    for name, out in (("gate", g), ("up", u)):
+        wq, wsc = C.quant_rowwise(ws[name], 0)
+        want, *_ = Q.qlinear(bits(x), 0, wq, wsc, None)
+        same(out, want, name)
+    h = torch.nn.functional.silu(g) * u
+    wq, wsc = C.quant_rowwise(ws["down"], 0)
+    want, *_ = Q.qlinear(bits(h), 0, wq, wsc, None)
+    same(mlp.down(h), want, "down")
+    assert mlp(x).shape == (M, H)
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
