@@ -33,13 +33,23 @@ constexpr int HALF_BYTES = 128 * FBK;        // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int EPI_ROW = 256 + 16;            // epilogue staging row: 256 B payload + 16 B pad
 constexpr int EPI_WAVE = 64 * EPI_ROW;       // 17 KiB per wave
-constexpr int LDS_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
+constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
+constexpr int SCALE_OFF = STAGE_BYTES;        // + 1 KiB row scales (256 f32) + 1 KiB column scales: DMA'd in the prologue
+constexpr int LDS_BYTES = STAGE_BYTES + 2048;
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 __device__ __forceinline__ void glds16(const int8_t* g, uint8_t* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+// LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form: no 64-bit VALU address math beside the MFMAs.
+// base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written and restored inside
+// the statement (cdna guide §5.7).  hipcc does not count this load: the K-loop waits with explicit vmcnt(0).
+__device__ __forceinline__ void glds16_sbase(const int8_t* base, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 
 // XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
@@ -59,11 +69,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int OUT, int SHAPE, int ABL>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
-                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg) {
+                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps) {
     // ablation bits (dev builds only): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue, 16 direct epilogue
     constexpr bool DBG = ABL != 0;
     constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
+    constexpr bool no_vmwait = ABL & 32, no_barrier = ABL & 64;   // timing-only: results are wrong
+    constexpr bool no_store = ABL & 128, const_scale = ABL & 256; // epilogue split: skip global stores / skip scale loads
     (void)dbg;
+    // dev builds: wave 0 stamps shader cycles + 100 MHz real time around the whole kernel body (own buffer, never an output)
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if constexpr (DBG) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int8_t* gP = W + (int64_t)n0 * ldw;   // uniform; advanced by FBK per staged K-tile
     const int8_t* gQ = X + (int64_t)m0 * ldx;
     const int piece_off = w * 2048;             // pieces w*2 and w*2+1 of a half-tile
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;   // LDS byte address of the array
 
     // ---- fragment read addresses (lane part)
     constexpr int NPI = (SHAPE == 16) ? 4 : 2;     // P tiles per half (64 rows)
@@ -147,8 +163,13 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         constexpr int g = decltype(gc)::value;
         constexpr int isQ = (g >= 2 && g < 6), h = (g >= 4), jj = g & 1;
         if (!no_dma) {
+#ifndef PQ_GLDS_BUILTIN
+            const uint32_t la = smem_base + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
+            glds16_sbase(isQ ? gQ : gP, isQ ? offQ[h][jj] : offP[h][jj], la);
+#else
             uint8_t* l = smem + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
             glds16(isQ ? gQ + offQ[h][jj] : gP + offP[h][jj], l);
+#endif
         }
         if constexpr (g == 7) { gP += FBK; gQ += FBK; }
     };
@@ -176,8 +197,18 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         static_for<NM>([&](auto xc) {
             constexpr int x = decltype(xc)::value, ks = x / (NPI * NQJ), i = (x / NQJ) % NPI, j = x % NQJ;
             if (!no_mma) {
+                // Inline asm with an AGPR-class ("a") accumulator: the accumulators live in the AGPR half of the
+                // register file, so LDS-return writes and fragment reads no longer compete with accumulator traffic
+                // on the arch-VGPR ports (measured +11 % MFMA+LDS throughput, tools/ubench/mfma_lds.hip).  hipcc does
+                // not see an MFMA here: no accumulator is re-used within 8 instructions, and the epilogue pads
+                // before its first v_accvgpr_read.
+#ifdef PQ_MFMA_ASM_AGPR
+                if constexpr (SHAPE == 16) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c[i][j]) : "v"(fp[i][ks]), "v"(fq[j][ks]));
+                else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c[i][j]) : "v"(fp[i][ks]), "v"(fq[j][ks]));
+#else
                 if constexpr (SHAPE == 16) c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
                 else c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             slot(xc);
@@ -194,6 +225,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     //   --- vmcnt(0) + lgkmcnt(0) + s_barrier: tile kt+1 visible to all, tile kt's buffer free ---
     //   q2: MFMA acc[1][0] (fPb, fQa)   | slots: read P0[kt+1] -> fPa, then DMA tile kt+2
     //   q3: MFMA acc[1][1] (fPb, fQb)   | slots: read Q0[kt+1] -> fQa (free after q2)
+    // grp (compile-time) = w >> 2: SIMD partners (waves w and w+4) are in different groups and issue their DMA
+    // pieces on alternating slots, never in the same MFMA shadow (an LDS-DMA issue costs the issuing wave
+    // 60-185 cycles; two partners issuing together leave the matrix pipe idle).
     auto tile = [&](int kt, auto has_next, auto has_next2) {
         const int bufoff = (kt & 1) * BUF_BYTES;
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value;
@@ -206,23 +240,52 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
         });
         if constexpr (next) {
-            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
-            __builtin_amdgcn_s_barrier();
+            if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+            else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
+            if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
+#ifdef PQ_STAGGER
+            if (wp) __builtin_amdgcn_s_sleep(PQ_STAGGER);   // time-shift SIMD partners so their DMA issues interleave
+#endif
         }
-        mma(acc[1][0], fPb, fQa, [&](auto xc) {
-            constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-            if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
-        });
-        mma(acc[1][1], fPb, fQb, [&](auto xc) {
-            constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
-        });
+        if constexpr (SHAPE == 16) {
+            // 32 slots over q2+q3: odd slots carry the LDS reads of the next tile's first fragments, every 4th slot
+            // one of the 8 DMA pieces (spread out: an LDS-DMA issue costs the issuing wave 60-185 cycles)
+            mma(acc[1][0], fPb, fQa, [&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                if constexpr (x % 2 == 1) { if constexpr (next) readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x / 2>{}); }
+                else if constexpr (next2 && x % 4 == 0) dma_item(kt & 1, std::integral_constant<int, x / 4>{});
+            });
+            mma(acc[1][1], fPb, fQb, [&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                if constexpr (x % 2 == 1) { if constexpr (next && x < 8) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, std::integral_constant<int, x / 2>{}); }
+                else if constexpr (next2 && x % 4 == 0) dma_item(kt & 1, std::integral_constant<int, 4 + x / 4>{});
+            });
+        } else {
+            mma(acc[1][0], fPb, fQa, [&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+                if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
+            });
+            mma(acc[1][1], fPb, fQb, [&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
+            });
+        }
     };
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
 
-    // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, first fragments in registers
+    // ---- prologue: the tile's 256 row scales and 256 column scales go to LDS by DMA (waves 0 and 1, 4 floats per
+    // lane, clamped at the matrix edge) so the epilogue never waits on a global load; then tiles 0 and 1.
+    if constexpr (OUT != OUT_I32) {
+        if (w < 2) {
+            const int base = w == 0 ? m0 : n0, lim = w == 0 ? M : N;
+            int e0 = base + lane * 4;
+            e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
+            const float* src = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + SCALE_OFF + w * 1024), 16, 0, 0);
+        }
+    }
     stage_tile(0);
     if (NT > 1) { stage_tile(1); __builtin_amdgcn_s_waitcnt(0x0078); }   // vmcnt(8) lgkmcnt(0)
     else { __builtin_amdgcn_s_waitcnt(0x0070); }                          // vmcnt(0) lgkmcnt(0)
@@ -235,6 +298,24 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     if (kt + 1 < NT) { tile(kt, yes, no); ++kt; }
     tile(kt, no, no);
 
+    if constexpr (DBG) {
+        if (stamps != nullptr && threadIdx.x == 0) {
+            stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - st_c0;
+            stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        }
+    }
+    // the asm MFMAs are invisible to hipcc's hazard recogniser: retire the last ones before any accumulator read
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // ...and make every accumulator read data-dependent on that pad (volatile asms keep their order; a plain
+    // v_accvgpr_read could otherwise be hoisted right behind the MFMA that defines it and read the stale value)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                for (int j = 0; j < NQJ; ++j) asm volatile("" : "+a"(acc[a][b][i][j]));
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
     if (no_epi) {   // keep the accumulators live, write (almost) nothing
         int sink = 0;
@@ -276,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                 for (int j = 0; j < NQJ; ++j) {
                     const int ml = hQ * 32 + j * SHAPE + dcol;
                     float as = 1.0f;
-                    if constexpr (OUT != OUT_I32) as = epi.a_scale[wm0 + ml];
+                    if constexpr (OUT != OUT_I32 && !const_scale) as = reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * 64 + ml];
 #pragma unroll
                     for (int hP = 0; hP < 2; ++hP) {
                         if (NPASS == 2 && hP != pass) continue;
@@ -288,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                                 const acc_t& c = acc[hP][hQ][i][j];
                                 v4f bs = {1.f, 1.f, 1.f, 1.f};
                                 float bf[4] = {0.f, 0.f, 0.f, 0.f};
-                                if constexpr (OUT != OUT_I32) {
-                                    bs = *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + nl);
+                                if constexpr (OUT != OUT_I32 && !const_scale) {
+                                    bs = *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * 128 + nl) * 4);
                                     if (has_bias) {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
@@ -312,7 +393,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                 const int r = it * 4 + (lane >> 4), ch = lane & 15;
                 const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ch * 16);
                 uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
-                *reinterpret_cast<v4u*>(dst) = v;
+                if constexpr (no_store) { if (v[0] == 0x12345678u && v[3] == 0x0badf00du) *reinterpret_cast<v4u*>(dst) = v; }
+                else *reinterpret_cast<v4u*>(dst) = v;
             }
             if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before pass 1 overwrites
         }
@@ -374,6 +456,8 @@ bool gemm_fast_eligible(const int8_t* A, int64_t lda, const int8_t* B, int64_t l
            M < (1 << 30) && N < (1 << 30) && lda < (1 << 23) && ldb < (1 << 23);
 }
 
+unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev_set_stamp_buffer
+void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
 template <int OUT, int SHAPE>
@@ -384,14 +468,14 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && SHAPE == 16) {
         switch (gemm_debug_flags()) {
-#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n); return;
-            PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16)
+#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps); return;
+            PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(128) PQ_ABL(256) PQ_ABL(384) PQ_ABL(1024)
 #undef PQ_ABL
             default: break;
         }
     }
 #endif
-    gemm_s8_sp256<OUT, SHAPE, 0><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0);
+    gemm_s8_sp256<OUT, SHAPE, 0><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr);
 }
 
 #define PQ_INST(OUT, SHAPE) \

@@ -14,6 +14,7 @@ template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, i
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
+void set_stamp_buffer(unsigned long long*);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -159,6 +160,10 @@ int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits
     pq::launch_fast_quotient_check(x_bits, s_bits, n, mismatches, static_cast<hipStream_t>(stream));
     return check_launch("pq_selftest_fast_quotient");
 }
+
+#ifdef PQ_ABLATION_BUILD
+void pq_dev_set_stamp_buffer(unsigned long long* p) { pq::set_stamp_buffer(p); }
+#endif
 
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     // alignment of the pointers is unknown here: assume 16-byte aligned bases
