@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--mode", choices=["dp", "tp"], default="dp")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -134,8 +135,9 @@ def main():
         if tp:
             dist.all_gather_into_tensor(y_full, y.view(-1))
 
-    # hipGraph capture of the two launches (the collective, if any, stays outside the graph)
+    # hipGraph capture: S consecutive steps (2 launches each) per replay; the collective of --mode tp stays outside.
     use_graph = not args.no_graph
+    S = 1 if tp else max(1, min(args.graph_steps, args.steps))
     graph = None
     if use_graph:
         try:
@@ -146,18 +148,26 @@ def main():
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                k1(); k3()
+                for _ in range(S):
+                    k1(); k3()
         except Exception as e:   # report, never silently change what is measured
             print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
             graph = None
+    if graph is None:
+        S = 1
 
-    def step():
+    def run_steps(n):
+        """exactly n steps: n // S graph replays of S steps + the remainder eagerly"""
         if graph is not None:
-            graph.replay()
-            if tp:
-                dist.all_gather_into_tensor(y_full, y.view(-1))
+            for _ in range(n // S):
+                graph.replay()
+                if tp:
+                    dist.all_gather_into_tensor(y_full, y.view(-1))
+            for _ in range(n % S):
+                step_eager()
         else:
-            step_eager()
+            for _ in range(n):
+                step_eager()
 
     def fence():
         torch.cuda.synchronize()
@@ -165,14 +175,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     e1.record()
     fence()
     dt = time.perf_counter() - t0
@@ -201,7 +209,7 @@ def main():
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
         "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
                    "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" if tp else f"dp{world} over tokens, replicated int8 weights"),
-                   "launch": "hipgraph" if graph is not None else "eager",
+                   "launch": (f"hipgraph x{S} steps/replay" if graph is not None else "eager"),
                    "gemm_variant": lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()},
         "roofline": {"bound": "mfma", "kernel": "gemm_s8_sp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
                      "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(2.0 * M * n_local * K / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),

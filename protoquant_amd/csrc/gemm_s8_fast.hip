@@ -36,6 +36,11 @@ constexpr int EPI_WAVE = 64 * EPI_ROW;       // 17 KiB per wave
 constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
 constexpr int SCALE_OFF = STAGE_BYTES;        // + 1 KiB row scales (256 f32) + 1 KiB column scales: DMA'd in the prologue
 constexpr int LDS_BYTES = STAGE_BYTES + 2048;
+#ifdef PQ_DMA_SPREAD
+constexpr bool DMA_SPREAD = true;
+#else
+constexpr bool DMA_SPREAD = false;
+#endif
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -247,9 +252,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             if (wp) __builtin_amdgcn_s_sleep(PQ_STAGGER);   // time-shift SIMD partners so their DMA issues interleave
 #endif
         }
-        if constexpr (SHAPE == 16) {
-            // 32 slots over q2+q3: odd slots carry the LDS reads of the next tile's first fragments, every 4th slot
-            // one of the 8 DMA pieces (spread out: an LDS-DMA issue costs the issuing wave 60-185 cycles)
+        if constexpr (SHAPE == 16 && DMA_SPREAD) {
+            // alternative schedule (dev): odd slots carry the LDS reads, every 4th slot one of the 8 DMA pieces.
+            // Fewer loop cycles (75 K vs 79 K) but a lower clock at equal power: same time on random bytes,
+            // 5 % slower on gaussian codes.  Kept for experiments only.
             mma(acc[1][0], fPb, fQa, [&](auto xc) {
                 constexpr int x = decltype(xc)::value;
                 if constexpr (x % 2 == 1) { if constexpr (next) readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x / 2>{}); }
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
         }
     }
+#ifdef PQ_MFMA_ASM_AGPR
     // the asm MFMAs are invisible to hipcc's hazard recogniser: retire the last ones before any accumulator read
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ...and make every accumulator read data-dependent on that pad (volatile asms keep their order; a plain
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             for (int i = 0; i < NPI; ++i)
 #pragma unroll
                 for (int j = 0; j < NQJ; ++j) asm volatile("" : "+a"(acc[a][b][i][j]));
+#endif
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
     if (no_epi) {   // keep the accumulators live, write (almost) nothing
         int sink = 0;
