@@ -253,38 +253,42 @@ __global__ __launch_bounds__(256) void quant_rowwise_generic(const void* __restr
 
 // ------------------------------------------------------------------------------------------------
 // K2: reduction along the strided axis.  Launch 1: column amax (bit patterns of non-negative floats
-// order like unsigned ints -> atomicMax on uint32) into `scale`; launch 2: encode with scale_of()
-// computed per thread once for its columns; launch 3: scale[c] = scale_of(amax[c]) in place.
+// order like unsigned ints -> atomicMax on uint32) into `scale`; launch 2: encode with the per-column
+// scale (division-free exact quotient when every column of the wave allows it); launch 3:
+// scale[c] = scale_of(amax[c]) in place.  Loads are unrolled 4 rows deep (independent, clamped addresses).
 template <int DT, bool VEC>
 __global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, int64_t rows, int64_t ncolv,
                                                 int64_t ldx_bytes, uint32_t* __restrict__ amax_bits, int rows_per_block) {
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t cv = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cvr = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cv = cvr < ncolv ? cvr : ncolv - 1;            // clamped: duplicates do not change a max
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float m[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) m[j] = 0.0f;
-    if (cv < ncolv) {
-        for (int64_t r = r0 + w; r < r1; r += 4) {
-            const uint8_t* p = x + r * ldx_bytes + cv * (VEC ? 16 : Elem<DT>::kBytes);
-            if constexpr (VEC) {
-                float f[EPV];
-                Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f);
+    const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
+    for (int64_t r = r0 + w; r < r1; r += 16) {
+        float f[4][EPV];
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) m[j] = amax_step(m[j], f[j]);
-            } else {
-                m[0] = amax_step(m[0], Elem<DT>::to_f32(*reinterpret_cast<const S*>(p)));
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+            const uint8_t* p = col + rr * ldx_bytes;
+            if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
+            else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) m[j] = amax_step(m[j], f[u][j]);
     }
     __shared__ float part[4][64][EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) part[w][lane][j] = m[j];
     __syncthreads();
-    if (w == 0 && cv < ncolv) {
+    if (w == 0 && cvr < ncolv) {
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
             float a = m[j];
@@ -302,30 +306,51 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t cv = (int64_t)blockIdx.x * 64 + lane;
-    if (cv >= ncolv) return;
+    const int64_t cvr = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = cvr < ncolv;
+    const int64_t cv = live ? cvr : ncolv - 1;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float s[EPV];
+    float s[EPV], rcp[EPV];
+    bool ok = true;
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) s[j] = scale_of(amax[cv * EPV + j]);
-    for (int64_t r = r0 + w; r < r1; r += 4) {
-        const uint8_t* p = x + r * ldx_bytes + cv * (VEC ? 16 : Elem<DT>::kBytes);
-        int8_t* o = q + r * ldq + cv * EPV;
-        if constexpr (VEC) {
-            float f[EPV];
-            Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f);
+    for (int j = 0; j < EPV; ++j) {
+        s[j] = scale_of(amax[cv * EPV + j]);
+        rcp[j] = 1.0f / s[j];
+        ok = ok && scale_fast_ok(s[j]);
+    }
+    const bool fast = __builtin_amdgcn_ballot_w64(!ok) == 0;      // wave-uniform
+    const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
+    for (int64_t r = r0 + w; r < r1; r += 16) {
+        float f[4][EPV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+            const uint8_t* p = col + rr * ldx_bytes;
+            if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
+            else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + 4 * u;
             int c[EPV];
+            if (fast) {
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) c[j] = code_of(f[j], s[j]);
-            if constexpr (EPV == 8) {
-                v2u ov = {pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])};
-                *reinterpret_cast<v2u*>(o) = ov;
+                for (int j = 0; j < EPV; ++j) {
+                    const float qf = quotient_fast(f[u][j], s[j], rcp[j]);
+                    const uint32_t mb = __builtin_bit_cast(uint32_t, qf + kMagic);
+                    c[j] = (qf != qf) ? 0 : (int)(int8_t)(mb & 0xFFu);          // Q5: NaN -> 0
+                }
             } else {
-                *reinterpret_cast<uint32_t*>(o) = pack4(c[0], c[1], c[2], c[3]);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) c[j] = code_of(f[u][j], s[j]);
             }
-        } else {
-            *o = (int8_t)code_of(Elem<DT>::to_f32(*reinterpret_cast<const S*>(p)), s[0]);
+            if (live && rr < r1) {
+                int8_t* o = q + rr * ldq + cv * EPV;
+                if constexpr (EPV == 8) *reinterpret_cast<v2u*>(o) = v2u{pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])};
+                else if constexpr (EPV == 4) *reinterpret_cast<uint32_t*>(o) = pack4(c[0], c[1], c[2], c[3]);
+                else *o = (int8_t)c[0];
+            }
         }
     }
 }
@@ -336,35 +361,46 @@ __global__ void col_finalize(float* __restrict__ scale, int64_t cols) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// dequant: out = cast_rne(f32(q) * scale[kept axis]).  Vector path: 16 codes per thread.
+// dequant: out = cast_rne(f32(q) * scale[kept axis]).  Vector path: every lane STORES 16 contiguous bytes
+// (8 half / 4 f32 results), so a wave-instruction writes 1 KiB of whole lines and reads 512/256 B contiguous.
 template <int ODT, bool VEC>
 __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__ q, int64_t ldq,
                                                       const float* __restrict__ scale, int axis, int64_t rows,
                                                       int64_t ncolv, void* __restrict__ out, int64_t ldo) {
     using S = typename Elem<ODT>::store_t;
-    constexpr int EPV = VEC ? 16 : 1;
-    const int64_t cv = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    constexpr int EPT = VEC ? 16 / (int)sizeof(S) : 1;      // 8 (half) or 4 (f32) codes per thread
+    const int64_t cvr = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cv >= ncolv || r >= rows) return;
-    const int8_t* p = q + r * ldq + cv * EPV;
-    S* o = reinterpret_cast<S*>(out) + r * ldo + cv * EPV;
+    if (cvr >= ncolv || r >= rows) return;
+    const int8_t* p = q + r * ldq + cvr * EPT;
+    S* o = reinterpret_cast<S*>(out) + r * ldo + cvr * EPT;
     if constexpr (VEC) {
-        const v4u v = *reinterpret_cast<const v4u*>(p);
-        const float sr = axis == 0 ? 0.0f : scale[r];
-        S res[16];
+        uint32_t raw[EPT / 4];
+        if constexpr (EPT == 8) { const v2u t = *reinterpret_cast<const v2u*>(p); raw[0] = t[0]; raw[1] = t[1]; }
+        else raw[0] = *reinterpret_cast<const uint32_t*>(p);
+        float scv[EPT];
+        if (axis == 0) {                       // per-column scales: EPT consecutive floats, 16-byte vector loads
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int code = (int)(int8_t)((v[j >> 2] >> (8 * (j & 3))) & 0xFF);
-            const float s = axis == 0 ? scale[cv * 16 + j] : sr;
-            res[j] = Elem<ODT>::from_f32((float)code * s);
+            for (int g = 0; g < EPT / 4; ++g) {
+                const v4f t4 = *reinterpret_cast<const v4f*>(scale + cvr * EPT + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) scv[4 * g + j] = t4[j];
+            }
+        } else {
+            const float sr = scale[r];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) scv[j] = sr;
         }
-        constexpr int NV = 16 * (int)sizeof(S) / 16;
-        const v4u* rv = reinterpret_cast<const v4u*>(res);
+        S res[EPT];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) reinterpret_cast<v4u*>(o)[k] = rv[k];
+        for (int j = 0; j < EPT; ++j) {
+            const int code = (int)(int8_t)((raw[j >> 2] >> (8 * (j & 3))) & 0xFF);
+            res[j] = Elem<ODT>::from_f32((float)code * scv[j]);
+        }
+        *reinterpret_cast<v4u*>(o) = *reinterpret_cast<const v4u*>(res);
     } else {
-        const float s = axis == 0 ? scale[cv] : scale[r];
-        *o = Elem<ODT>::from_f32((float)(*p) * s);
+        const float sc = axis == 0 ? scale[cvr] : scale[r];
+        *o = Elem<ODT>::from_f32((float)(*p) * sc);
     }
 }
 
@@ -432,9 +468,10 @@ void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
 template <int ODT>
 void dequant_dispatch(const int8_t* q, int64_t ldq, const float* scale, int axis, int64_t rows, int64_t cols,
                       void* out, int64_t ldo, hipStream_t st) {
-    const bool vec_ok = (cols % 16 == 0) && (ldq % 16 == 0) && aligned(q, 16) && aligned(out, 16) &&
-                        ((ldo * Elem<ODT>::kBytes) % 16 == 0);
-    const int64_t ncolv = vec_ok ? cols / 16 : cols;
+    constexpr int EPT = 16 / Elem<ODT>::kBytes;
+    const bool vec_ok = (cols % EPT == 0) && (ldq % EPT == 0) && aligned(q, EPT) && aligned(out, 16) &&
+                        ((ldo * Elem<ODT>::kBytes) % 16 == 0) && (axis != 0 || aligned(scale, 16));
+    const int64_t ncolv = vec_ok ? cols / EPT : cols;
     const dim3 grid((unsigned)((ncolv + 63) / 64), (unsigned)((rows + 3) / 4)), block(256);
     if (vec_ok) dequant_kernel<ODT, true><<<grid, block, 0, st>>>(q, ldq, scale, axis, rows, ncolv, out, ldo);
     else dequant_kernel<ODT, false><<<grid, block, 0, st>>>(q, ldq, scale, axis, rows, ncolv, out, ldo);
