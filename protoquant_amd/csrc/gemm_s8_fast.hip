@@ -283,8 +283,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     // ---- prologue: the tile's 256 row scales and 256 column scales go to LDS by DMA (waves 0 and 1, 4 floats per
     // lane, clamped at the matrix edge) so the epilogue never waits on a global load; then tiles 0 and 1.
+    // (only when both scale vectors are 16-byte aligned and at least 4 long; otherwise the direct epilogue is used)
+    const bool scales_in_lds = (OUT == OUT_I32) ||
+        ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
     if constexpr (OUT != OUT_I32) {
-        if (w < 2) {
+        if (scales_in_lds && w < 2) {
             const int base = w == 0 ? m0 : n0, lim = w == 0 ? M : N;
             int e0 = base + lane * 4;
             e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 128;                      // this wave's 64(m) x 128(n) block
 
     // staged path: whole block in range, 16-byte aligned rows
-    const bool staged = !direct_epi && (wm0 + 64 <= M) && (wn0 + 128 <= N) &&
+    const bool staged = !direct_epi && scales_in_lds && (wm0 + 64 <= M) && (wn0 + 128 <= N) &&
                         ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
     __builtin_amdgcn_s_barrier();     // every wave is done reading the K-loop buffers (uniform: all waves reach it)
     if (staged) {

@@ -171,6 +171,22 @@ def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, monkeypatch):
     same(pq.int_mm(torch.from_numpy(xq_want).cuda(), torch.from_numpy(wq).cuda()), acc_want, "acc")
 
 
+def test_qlinear_unaligned_scales_and_output(pq):
+    """Scale vectors / outputs that are only 4-byte aligned take the direct epilogue: same bits."""
+    rng = np.random.default_rng(21)
+    M, N, K = 256, 512, 256
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M + 1).astype(np.float32); ws = rng.random(N + 1).astype(np.float32)
+    want = Q.epilogue((a.astype(np.int64) @ b.astype(np.int64).T).astype(np.int32), xs[1:], ws[1:], None, 0)
+    xs_t = torch.from_numpy(xs).cuda()[1:]; ws_t = torch.from_numpy(ws).cuda()[1:]          # +4 bytes: unaligned
+    got = pq.qlinear_s8(torch.from_numpy(a).cuda(), xs_t, torch.from_numpy(b).cuda(), ws_t, None, torch.bfloat16)
+    same(got, want, "unaligned scales")
+    big = torch.empty((M, N + 8), dtype=torch.bfloat16, device="cuda")
+    out = big[:, 1:N + 1]                                                                   # 2-byte-aligned rows, ld = N + 8
+    pq.qlinear_s8(torch.from_numpy(a).cuda(), xs_t, torch.from_numpy(b).cuda(), ws_t, None, torch.bfloat16, out=out)
+    same(out.contiguous(), want, "unaligned output")
+
+
 def test_full_size_cfg2_properties(pq):
     """BASELINE config 2 (M=N=K=4096, bf16): size-independent checks + sampled exact parity.
     (a) xq/xs bit-exact vs the C oracle on all rows; (b) int32 accumulator exact vs int64 matmul on

@@ -1,0 +1,28 @@
+"""Dev tool: fused GEMM+epilogue throughput over the model shapes of BASELINE configs 3-5 (M x N x K)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import protoquant_amd as pq
+from protoquant_amd import _lib as L
+lib = L.lib()
+SHAPES = [(4096, 4096, 4096, "cfg2 / 8B q,o"), (2048, 11008, 4096, "cfg3 gate/up"), (2048, 4096, 11008, "cfg3 down"),
+          (4096, 1024, 4096, "8B k,v"), (4096, 14336, 4096, "8B gate/up"), (4096, 4096, 14336, "8B down"),
+          (4096, 128256, 4096, "lm_head"), (4096, 1024, 8192, "70B q/o shard"), (4096, 3584, 8192, "70B gate/up shard"),
+          (4096, 1024, 28672, "70B down shard"), (32, 512, 512, "cfg1"), (512, 4096, 4096, "M=512"), (8192, 8192, 8192, "8k cube")]
+def t(fn, it):
+    for _ in range(5): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it): fn()
+    b.record(); b.synchronize()
+    return a.elapsed_time(b) * 1e3 / it
+for M, N, K, name in SHAPES:
+    xq = torch.randint(-100, 101, (M, K), dtype=torch.int8, device="cuda"); wq = torch.randint(-100, 101, (N, K), dtype=torch.int8, device="cuda")
+    xs = torch.rand(M, device="cuda"); ws = torch.rand(N, device="cuda"); y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    f = lambda: lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, None, 0, st)
+    ops = 2.0 * M * N * K
+    us = t(f, 30 if ops > 1e12 else 100)
+    tiles = -(-M // 256) * -(-N // 256)
+    print(f"{name:22s} {M:5d} x {N:6d} x {K:5d}  tiles {tiles:5d} ({tiles/256:5.2f} waves)  {us:9.1f} us  {ops/us/1e6:7.1f} TOPS  {ops/us/1e6/50.33:5.1f} %  [{lib.pq_gemm_variant_name(M,N,K,K,K).decode()}]")
+    del xq, wq, y
