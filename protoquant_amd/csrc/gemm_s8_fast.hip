@@ -31,8 +31,8 @@ constexpr int FT = 256;          // tile edge (both m and n)
 constexpr int FBK = 128;         // K bytes per tile step
 constexpr int HALF_BYTES = 128 * FBK;        // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;    // 64 KiB
-constexpr int EPI_ROW = 256 + 16;            // epilogue staging row: 256 B payload + 16 B pad
-constexpr int EPI_WAVE = 64 * EPI_ROW;       // 17 KiB per wave
+constexpr int EPI_ROW = 256;                 // epilogue staging row: 16 chunks of 16 B, chunk c of row r at c ^ (r & 15)
+constexpr int EPI_WAVE = 64 * EPI_ROW;       // 16 KiB per wave
 constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
 constexpr int SCALE_OFF = STAGE_BYTES;        // + 1 KiB row scales (256 f32) + 1 KiB column scales: DMA'd in the prologue
 constexpr int LDS_BYTES = STAGE_BYTES + 2048;
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs[r], bf[r], has_bias);
                                 const int ncol = (NPASS == 2) ? (nl - pass * 64) : nl;
-                                uint8_t* d = sw + ml * EPI_ROW + ncol * OB;
+                                const int boff = ncol * OB;                              // byte offset inside the 256-B row
+                                uint8_t* d = sw + ml * EPI_ROW + ((((boff >> 4) ^ (ml & 15)) << 4) | (boff & 15));
                                 if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
                                 else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
                             }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 4 + (lane >> 4), ch = lane & 15;
-                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ch * 16);
+                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ((ch ^ (r & 15)) << 4));
                 uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
                 if constexpr (no_store) { if (v[0] == 0x12345678u && v[3] == 0x0badf00du) *reinterpret_cast<v4u*>(dst) = v; }
                 else *reinterpret_cast<v4u*>(dst) = v;

@@ -105,6 +105,40 @@ class qlinear(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
 
 
+class FusedQLinear(nn.Module):
+    """Horizontal fusion of projections that share one input (q/k/v, gate/up): the int8 weights are concatenated
+    along N, the activation is quantised ONCE and one GEMM launch fills all outputs (better tile count on 256 CUs
+    than separate N=1024 GEMMs).  Exact: weight scales are per output row, so concatenation changes no value.
+    forward() returns one tensor per fused projection (views of the fused output)."""
+
+    def __init__(self, parts):
+        super().__init__()
+        parts = list(parts)
+        if not parts or any(p.in_features != parts[0].in_features for p in parts):
+            raise ValueError("FusedQLinear: projections must share in_features")
+        if any((p.bias is None) != (parts[0].bias is None) for p in parts):
+            raise ValueError("FusedQLinear: either all or none of the projections may have a bias")
+        self.in_features = parts[0].in_features
+        self.splits = [p.out_features for p in parts]
+        self.out_features = sum(self.splits)
+        self.register_buffer("wq", torch.cat([p.wq for p in parts], dim=0).contiguous())
+        self.register_buffer("ws", torch.cat([p.ws for p in parts], dim=0).contiguous())
+        if parts[0].bias is not None:
+            self.register_buffer("bias", torch.cat([p.bias for p in parts], dim=0).contiguous())
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_linears(cls, *linears: nn.Linear) -> "FusedQLinear":
+        return cls([qlinear.from_linear(l) for l in linears])
+
+    def forward(self, x: torch.Tensor):
+        xq = quantize(x, axis=-1)
+        y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, x.dtype)
+        y = y.reshape(*x.shape[:-1], self.out_features)
+        return torch.split(y, self.splits, dim=-1)
+
+
 def swap_linears(model: nn.Module, predicate=None) -> nn.Module:
     """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place."""
     for name, child in list(model.named_children()):

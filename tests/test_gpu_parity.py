@@ -302,6 +302,59 @@ def test_swap_linears_on_mlp(pq):
     assert mlp(x).shape == (M, H)
 
 
+def test_fused_qkv_matches_separate(pq):
+    """Horizontal fusion (q/k/v share the activation): outputs bit-identical to three separate qlinears."""
+    torch.manual_seed(8)
+    H = 512
+    lq, lk, lv = (torch.nn.Linear(H, n, bias=True, device="cuda", dtype=torch.bfloat16) for n in (512, 128, 128))
+    x = torch.randn(3, 100, H, device="cuda", dtype=torch.bfloat16)
+    fused = pq.FusedQLinear.from_linears(lq, lk, lv)
+    outs = fused(x)
+    for lin, got in zip((lq, lk, lv), outs):
+        want = pq.qlinear.from_linear(lin)(x)
+        assert got.shape == want.shape and torch.equal(got.contiguous().view(torch.int16), want.view(torch.int16))
+
+
+def test_full_size_cfg3_mlp_block(pq):
+    """BASELINE config 3: Llama MLP block 4096 -> 11008 -> 4096 at seq 2048, all three projections as qlinear.
+    Every projection is checked on 64 sampled token rows x all output channels, bit-exact vs the oracle
+    (int64 accumulators + QSPEC epilogue), plus full xq/xs parity of both activation quantisations."""
+    M, H, I = 2048, 4096, 11008
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(M, H, generator=g).to(torch.bfloat16)
+    ws = {n: (torch.randn(o, i, generator=g) * 0.02).to(torch.bfloat16) for n, (o, i) in
+          (("gate", (I, H)), ("up", (I, H)), ("down", (H, I)))}
+    mods = {}
+    for n, w in ws.items():
+        lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device="cuda", dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(w.cuda())
+        mods[n] = pq.qlinear.from_linear(lin)
+    fused = pq.FusedQLinear([mods["gate"], mods["up"]])
+    xg = x.cuda()
+    gate, up = fused(xg)
+    h = (torch.nn.functional.silu(gate.float()) * up.float()).to(torch.bfloat16)      # stock torch-ROCm elementwise
+    y = mods["down"](h)
+    rows = np.random.default_rng(1).choice(M, 64, replace=False)
+    rt = torch.from_numpy(rows).cuda()
+
+    def check(name, inp_bits, out, out_name):
+        wq, wsc = C.quant_rowwise(bits(ws[name]), 0)
+        same(mods[name].wq, wq, name + " wq")
+        xq, xs = C.quant_rowwise(inp_bits, 0)
+        acc = (xq[rows].astype(np.int64) @ wq.astype(np.int64).T).astype(np.int32)
+        same(out[rt].contiguous(), Q.epilogue(acc, xs[rows], wsc, None, 0), out_name)
+        return xq, xs
+
+    xq, xs = check("gate", bits(x), gate, "gate rows")
+    check("up", bits(x), up, "up rows")
+    q = pq.quantize(xg)
+    same(q.int_data, xq, "xq cfg3"); same(q.scale, xs, "xs cfg3")
+    hq, hs = check("down", bits(h), y, "down rows")
+    qh = pq.quantize(h)
+    same(qh.int_data, hq, "hq cfg3"); same(qh.scale, hs, "hs cfg3")
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
