@@ -203,7 +203,7 @@ def main():
     gemm_bytes = M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local)
 
     out = {
-        "metric": "int8 TOPS, fused qlinear (row-quant + s8 MFMA GEMM + dequant epilogue)",
+        "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
         "value": round(value, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",

@@ -18,8 +18,10 @@
 //     issued+retired its last read of tile t (so tile t's buffer can be refilled with tile t+2) and
 //     has waited for its own DMA pieces of tile t+1 (so tile t+1 is visible to all after the barrier).
 //     Every DMA therefore has a whole K-tile of MFMA time (~2000 cycles) to land.
-//   * Epilogue: scales applied in registers, tile transposed through LDS (per-wave private region),
-//     written with 16-byte stores as 256-byte row segments.
+//   * Epilogue: the tile's scales are DMA'd to LDS in the prologue; QSPEC E1-E4 in registers; the tile is
+//     transposed through a wave-private, XOR-swizzled LDS region and written with 16-byte stores as
+//     256-byte row segments.
+//   * Dev builds (make ABLATION=1) add compile-time ablated instantiations + cycle/clock stamps (tools/ablate.py).
 #include <cstdlib>
 #include <type_traits>
 
@@ -33,21 +35,13 @@ constexpr int HALF_BYTES = 128 * FBK;        // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int EPI_ROW = 256;                 // epilogue staging row: 16 chunks of 16 B, chunk c of row r at c ^ (r & 15)
 constexpr int EPI_WAVE = 64 * EPI_ROW;       // 16 KiB per wave
-constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 136 KiB
+constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 128 KiB
 constexpr int SCALE_OFF = STAGE_BYTES;        // + 1 KiB row scales (256 f32) + 1 KiB column scales: DMA'd in the prologue
 constexpr int LDS_BYTES = STAGE_BYTES + 2048;
-#ifdef PQ_DMA_SPREAD
-constexpr bool DMA_SPREAD = true;
-#else
-constexpr bool DMA_SPREAD = false;
-#endif
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-__device__ __forceinline__ void glds16(const int8_t* g, uint8_t* l) {
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
 // LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form: no 64-bit VALU address math beside the MFMAs.
 // base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written and restored inside
 // the statement (cdna guide §5.7).  hipcc does not count this load: the K-loop waits with explicit vmcnt(0).
@@ -168,13 +162,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         constexpr int g = decltype(gc)::value;
         constexpr int isQ = (g >= 2 && g < 6), h = (g >= 4), jj = g & 1;
         if (!no_dma) {
-#ifndef PQ_GLDS_BUILTIN
             const uint32_t la = smem_base + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
             glds16_sbase(isQ ? gQ : gP, isQ ? offQ[h][jj] : offP[h][jj], la);
-#else
-            uint8_t* l = smem + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
-            glds16(isQ ? gQ + offQ[h][jj] : gP + offP[h][jj], l);
-#endif
         }
         if constexpr (g == 7) { gP += FBK; gQ += FBK; }
     };
@@ -202,18 +191,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         static_for<NM>([&](auto xc) {
             constexpr int x = decltype(xc)::value, ks = x / (NPI * NQJ), i = (x / NQJ) % NPI, j = x % NQJ;
             if (!no_mma) {
-                // Inline asm with an AGPR-class ("a") accumulator: the accumulators live in the AGPR half of the
-                // register file, so LDS-return writes and fragment reads no longer compete with accumulator traffic
-                // on the arch-VGPR ports (measured +11 % MFMA+LDS throughput, tools/ubench/mfma_lds.hip).  hipcc does
-                // not see an MFMA here: no accumulator is re-used within 8 instructions, and the epilogue pads
-                // before its first v_accvgpr_read.
-#ifdef PQ_MFMA_ASM_AGPR
-                if constexpr (SHAPE == 16) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c[i][j]) : "v"(fp[i][ks]), "v"(fq[j][ks]));
-                else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c[i][j]) : "v"(fp[i][ks]), "v"(fq[j][ks]));
-#else
                 if constexpr (SHAPE == 16) c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
                 else c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             slot(xc);
@@ -230,9 +209,6 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     //   --- vmcnt(0) + lgkmcnt(0) + s_barrier: tile kt+1 visible to all, tile kt's buffer free ---
     //   q2: MFMA acc[1][0] (fPb, fQa)   | slots: read P0[kt+1] -> fPa, then DMA tile kt+2
     //   q3: MFMA acc[1][1] (fPb, fQb)   | slots: read Q0[kt+1] -> fQa (free after q2)
-    // grp (compile-time) = w >> 2: SIMD partners (waves w and w+4) are in different groups and issue their DMA
-    // pieces on alternating slots, never in the same MFMA shadow (an LDS-DMA issue costs the issuing wave
-    // 60-185 cycles; two partners issuing together leave the matrix pipe idle).
     auto tile = [&](int kt, auto has_next, auto has_next2) {
         const int bufoff = (kt & 1) * BUF_BYTES;
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value;
@@ -248,35 +224,16 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
             else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
             if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
-#ifdef PQ_STAGGER
-            if (wp) __builtin_amdgcn_s_sleep(PQ_STAGGER);   // time-shift SIMD partners so their DMA issues interleave
-#endif
         }
-        if constexpr (SHAPE == 16 && DMA_SPREAD) {
-            // alternative schedule (dev): odd slots carry the LDS reads, every 4th slot one of the 8 DMA pieces.
-            // Fewer loop cycles (75 K vs 79 K) but a lower clock at equal power: same time on random bytes,
-            // 5 % slower on gaussian codes.  Kept for experiments only.
-            mma(acc[1][0], fPb, fQa, [&](auto xc) {
-                constexpr int x = decltype(xc)::value;
-                if constexpr (x % 2 == 1) { if constexpr (next) readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x / 2>{}); }
-                else if constexpr (next2 && x % 4 == 0) dma_item(kt & 1, std::integral_constant<int, x / 4>{});
-            });
-            mma(acc[1][1], fPb, fQb, [&](auto xc) {
-                constexpr int x = decltype(xc)::value;
-                if constexpr (x % 2 == 1) { if constexpr (next && x < 8) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, std::integral_constant<int, x / 2>{}); }
-                else if constexpr (next2 && x % 4 == 0) dma_item(kt & 1, std::integral_constant<int, 4 + x / 4>{});
-            });
-        } else {
-            mma(acc[1][0], fPb, fQa, [&](auto xc) {
-                constexpr int x = decltype(xc)::value;
-                if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-                if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
-            });
-            mma(acc[1][1], fPb, fQb, [&](auto xc) {
-                constexpr int x = decltype(xc)::value;
-                if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
-            });
-        }
+        mma(acc[1][0], fPb, fQa, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+            if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
+        });
+        mma(acc[1][1], fPb, fQb, [&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
+        });
     };
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
@@ -313,20 +270,6 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
         }
     }
-#ifdef PQ_MFMA_ASM_AGPR
-    // the asm MFMAs are invisible to hipcc's hazard recogniser: retire the last ones before any accumulator read
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // ...and make every accumulator read data-dependent on that pad (volatile asms keep their order; a plain
-    // v_accvgpr_read could otherwise be hoisted right behind the MFMA that defines it and read the stale value)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < NPI; ++i)
-#pragma unroll
-                for (int j = 0; j < NQJ; ++j) asm volatile("" : "+a"(acc[a][b][i][j]));
-#endif
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
     if (no_epi) {   // keep the accumulators live, write (almost) nothing
         int sink = 0;
