@@ -8,16 +8,21 @@ lib = L.lib()
 SHAPES = [(4096, 4096, 4096, "cfg2 / 8B q,o"), (2048, 11008, 4096, "cfg3 gate/up"), (2048, 4096, 11008, "cfg3 down"),
           (4096, 1024, 4096, "8B k,v"), (4096, 14336, 4096, "8B gate/up"), (4096, 4096, 14336, "8B down"),
           (4096, 128256, 4096, "lm_head"), (4096, 1024, 8192, "70B q/o shard"), (4096, 3584, 8192, "70B gate/up shard"),
-          (4096, 1024, 28672, "70B down shard"), (32, 512, 512, "cfg1"), (512, 4096, 4096, "M=512"), (8192, 8192, 8192, "8k cube")]
+          (4096, 1024, 28672, "70B down shard"), (4096, 6144, 4096, "8B fused qkv"), (4096, 28672, 4096, "8B fused gate+up"), (32, 512, 512, "cfg1"), (512, 4096, 4096, "M=512"), (8192, 8192, 8192, "8k cube")]
 def t(fn, it):
-    for _ in range(5): fn()
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.5: fn()      # let the clocks settle under this kernel's load
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(it): fn()
     b.record(); b.synchronize()
     return a.elapsed_time(b) * 1e3 / it
 for M, N, K, name in SHAPES:
-    xq = torch.randint(-100, 101, (M, K), dtype=torch.int8, device="cuda"); wq = torch.randint(-100, 101, (N, K), dtype=torch.int8, device="cuda")
+    # gaussian int8 codes (sigma ~28, what per-token quantisation of N(0,1) data produces); uniform codes run ~20 % slower (power)
+    xq = (torch.randn(M, K, device="cuda") * 28).round().clamp(-127, 127).to(torch.int8)
+    wq = (torch.randn(N, K, device="cuda") * 28).round().clamp(-127, 127).to(torch.int8)
     xs = torch.rand(M, device="cuda"); ws = torch.rand(N, device="cuda"); y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     f = lambda: lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, None, 0, st)
