@@ -355,6 +355,28 @@ def test_full_size_cfg3_mlp_block(pq):
     same(qh.int_data, hq, "hq cfg3"); same(qh.scale, hs, "hs cfg3")
 
 
+def test_randomized_shape_sweep(pq):
+    """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
+    arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        M = int(rng.integers(1, 700)); N = int(rng.integers(1, 700))
+        K = int(rng.integers(1, 9)) * 128 if case % 2 == 0 else int(rng.integers(1, 600))
+        code = int(rng.integers(0, 3)); bias = bool(rng.integers(0, 2))
+        x = Q.from_f32((rng.standard_normal((M, K)) * rng.uniform(0.1, 10)).astype(np.float32), code)
+        w = Q.from_f32((rng.standard_normal((N, K)) * 0.05).astype(np.float32), code)
+        b = Q.from_f32((rng.standard_normal(N) * 0.1).astype(np.float32), code) if bias else None
+        wq, wsc = C.quant_rowwise(w, code)
+        y_want, xq_want, xs_want, acc_want = Q.qlinear(x, code, wq, wsc, b)
+        tag = f"case {case}: {M}x{N}x{K} dt{code} bias={bias}"
+        q = pq.quantize(to_gpu(x, code))
+        same(q.int_data, xq_want, tag + " xq"); same(q.scale, xs_want, tag + " xs")
+        wq_t, ws_t = torch.from_numpy(wq).cuda(), torch.from_numpy(wsc).cuda()
+        same(pq.int_mm(q.int_data, wq_t), acc_want, tag + " acc")
+        y = pq.qlinear_s8(q.int_data, q.scale, wq_t, ws_t, to_gpu(b, code) if bias else None, TD[code])
+        same(y, y_want, tag + " y")
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
