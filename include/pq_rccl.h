@@ -1,0 +1,44 @@
+/* pq_rccl.h — C-ABI of libpq_rccl.so: the one exchange step of the column-sharded configuration
+ * (BASELINE config 5): an RCCL all-gather of the per-rank output shards over xGMI plus the layout fix.
+ *
+ * Reference side: BASELINE.json's north_star ("shard the weight matrix column-wise across the 8 GPUs of one
+ * node with an RCCL all-gather over xGMI"); no reference source exists in the mount
+ * (/root/reference/CODE_OF_CONDUCT.md:1-80 only).  One process per GPU; the communicator is bootstrapped from a
+ * 128-byte unique id that rank 0 creates and the host distributes by any means (the Python side uses
+ * torch.distributed.broadcast_object_list).
+ *
+ * Conventions are those of pq_hip.h: caller-owned device buffers, stream-ordered, status codes (0 = OK,
+ * 1 bad argument, 5 workspace too small, 6 RCCL error), message via pq_rccl_last_error().
+ */
+#ifndef PQ_RCCL_H
+#define PQ_RCCL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ_RCCL_UNIQUE_ID_BYTES 128
+
+const char* pq_rccl_last_error(void);
+/* rank 0: fill id[128] (ncclGetUniqueId). */
+int32_t pq_comm_unique_id(void* id);
+/* every rank, after cudaSetDevice: *comm = ncclCommInitRank(nranks, id, rank). Blocks until all ranks arrive. */
+int32_t pq_comm_init_rank(void** comm, int32_t nranks, const void* id, int32_t rank);
+int32_t pq_comm_destroy(void* comm);
+
+/* y_shard[M, n_shard] (row-major, contiguous) on every rank  ->  y_full[M, nranks * n_shard] on every rank.
+ * An all-gather concatenates along the OUTERMOST axis, so the shards first land stacked [nranks, M, n_shard] in
+ * `workspace` (ncclAllGather), then one coalesced kernel interleaves them into y_full's columns.
+ * dtype: 0 bf16, 1 fp16, 2 f32.  workspace >= pq_allgather_cols_workspace_bytes(). */
+size_t pq_allgather_cols_workspace_bytes(int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype);
+int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void* y_full, int64_t M, int64_t n_shard,
+                          int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* the layout-fix kernel alone (stacked[nranks, M, n_shard] -> y_full[M, nranks*n_shard]); exposed for tests */
+int32_t pq_unstack_cols(const void* stacked, void* y_full, int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -3,7 +3,7 @@
 libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eager fallback."""
 from .qtensor import QTensor, quantize, dequantize
 from .qlinear import qlinear, qlinear_s8, int_mm, swap_linears, FusedQLinear
-from .sharded import ColumnShardedQLinear, gather_columns, shard_bounds
+from .sharded import ColumnShardedQLinear, RcclColumnGather, gather_columns, shard_bounds
 
 __all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "int_mm", "swap_linears", "FusedQLinear",
-           "ColumnShardedQLinear", "gather_columns", "shard_bounds"]
+           "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds"]

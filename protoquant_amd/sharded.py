@@ -55,16 +55,62 @@ def gather_columns(y_local: torch.Tensor, n_total: int, group=None, stacked: boo
     return torch.cat(parts, dim=1)
 
 
+class RcclColumnGather:
+    """The same exchange through the native C-ABI (include/pq_rccl.h): a dedicated RCCL communicator, one
+    ncclAllGather into a stacked workspace and the layout-fix kernel, all stream-ordered on torch's current
+    stream.  The 128-byte unique id is created on rank 0 and distributed with torch.distributed (any backend).
+    Requires equal shard widths (n_total % world == 0)."""
+
+    def __init__(self, group=None):
+        from . import _rccl
+        import ctypes
+        self._R, self._ct = _rccl, ctypes
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = [None]
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(_rccl.UNIQUE_ID_BYTES)
+            _rccl.check(_rccl.lib().pq_comm_unique_id(buf), "pq_comm_unique_id")
+            ident = [bytes(buf.raw)]
+        dist.broadcast_object_list(ident, src=0, group=group)
+        self._comm = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(ident[0], _rccl.UNIQUE_ID_BYTES)
+        _rccl.check(_rccl.lib().pq_comm_init_rank(ctypes.byref(self._comm), self.world, idbuf, self.rank), "pq_comm_init_rank")
+        self._ws = None
+
+    def __call__(self, y_local: torch.Tensor, n_total: int) -> torch.Tensor:
+        from . import _lib as L
+        if n_total % self.world or y_local.shape[1] * self.world != n_total:
+            raise ValueError("RcclColumnGather needs equal shards (n_total % world == 0)")
+        y_local = y_local.contiguous()
+        M, n = y_local.shape
+        code = L.dtype_code(y_local.dtype)
+        need = self._R.lib().pq_allgather_cols_workspace_bytes(self.world, M, n, code)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=y_local.device)
+        out = torch.empty((M, n_total), dtype=y_local.dtype, device=y_local.device)
+        with torch.cuda.device(y_local.device):
+            self._R.check(self._R.lib().pq_allgather_cols(self._comm, self.world, y_local.data_ptr(), out.data_ptr(), M, n, code,
+                                                          self._ws.data_ptr(), self._ws.numel(), L.stream_ptr(y_local)),
+                          "pq_allgather_cols")
+        return out
+
+    def close(self):
+        if self._comm:
+            self._R.check(self._R.lib().pq_comm_destroy(self._comm), "pq_comm_destroy")
+            self._comm = self._ct.c_void_p()
+
+
 class ColumnShardedQLinear(nn.Module):
     """qlinear whose int8 weight rows [n0:n1) live on this rank; forward returns the full y[..., N]."""
 
-    def __init__(self, local: qlinear, out_features: int, group=None):
+    def __init__(self, local: qlinear, out_features: int, group=None, native_gather: "RcclColumnGather | None" = None):
         super().__init__()
         self.local, self.out_features, self.group = local, out_features, group
         self.in_features = local.in_features
+        self.native_gather = native_gather          # optional: exchange through libpq_rccl.so instead of torch.distributed
 
     @classmethod
-    def from_linear(cls, lin: nn.Linear, group=None) -> "ColumnShardedQLinear":
+    def from_linear(cls, lin: nn.Linear, group=None, native_gather=None) -> "ColumnShardedQLinear":
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         lo, hi = shard_bounds(lin.out_features, world, rank)
         sub = nn.Linear(lin.in_features, hi - lo, bias=lin.bias is not None, device=lin.weight.device, dtype=lin.weight.dtype)
@@ -72,11 +118,14 @@ class ColumnShardedQLinear(nn.Module):
             sub.weight.copy_(lin.weight[lo:hi])
             if lin.bias is not None:
                 sub.bias.copy_(lin.bias[lo:hi])
-        return cls(qlinear.from_linear(sub), lin.out_features, group)
+        return cls(qlinear.from_linear(sub), lin.out_features, group, native_gather)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         xq = quantize(x, axis=-1)                                   # replicated activation: every rank runs K1 itself
         y_local = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.local.wq, self.local.ws,
                              self.local.bias, x.dtype)
-        y = gather_columns(y_local, self.out_features, self.group)
+        if self.native_gather is not None:
+            y = self.native_gather(y_local, self.out_features)
+        else:
+            y = gather_columns(y_local, self.out_features, self.group)
         return y.reshape(*x.shape[:-1], self.out_features)

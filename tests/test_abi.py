@@ -33,6 +33,20 @@ def test_library_exports_every_declared_symbol():
     assert L.pq_gemm_variant_name(5, 7, 3, 3, 3) == b"generic64"
 
 
+def test_rccl_library_exports_every_declared_symbol():
+    src = open(os.path.join(ROOT, "include", "pq_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(pq_[a-z0-9_]+)\s*\(", src)))
+    from protoquant_amd import _rccl
+    L = _rccl.lib()
+    for s in syms:
+        assert hasattr(L, s), f"libpq_rccl.so does not export {s}"
+    assert set(_rccl.EXPORTS) == set(syms)
+    assert L.pq_allgather_cols_workspace_bytes(8, 4096, 512, 0) == 8 * 4096 * 512 * 2
+    assert L.pq_allgather_cols(None, 8, None, None, 4, 4, 0, None, 0, None) == 1          # null communicator
+    assert L.pq_unstack_cols(None, None, 0, 4, 4, 0, None) == 1
+
+
 def test_argument_validation_needs_no_gpu():
     """Bad arguments are rejected before any HIP call."""
     from protoquant_amd import _lib

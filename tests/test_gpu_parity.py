@@ -271,6 +271,40 @@ def test_column_sharded_world1_matches_unsharded(pq):
             dist.destroy_process_group()
 
 
+def test_native_rccl_gather(pq):
+    """libpq_rccl.so: the layout-fix kernel on a synthetic 3-rank stacked buffer, and a real 1-rank RCCL
+    communicator (bootstrap, ncclAllGather, unstack) behind ColumnShardedQLinear — bit-identical to plain qlinear."""
+    import ctypes
+    import torch.distributed as dist
+    from protoquant_amd import _rccl
+    R = _rccl.lib()
+    for dt, code in ((torch.bfloat16, 0), (torch.float32, 2)):
+        for (G, M, n) in ((3, 37, 24), (2, 5, 7), (8, 64, 512)):
+            st = torch.randn(G, M, n, device="cuda").to(dt)
+            out = torch.empty((M, G * n), dtype=dt, device="cuda")
+            _rccl.check(R.pq_unstack_cols(st.data_ptr(), out.data_ptr(), G, M, n, code, torch.cuda.current_stream().cuda_stream), "unstack")
+            assert torch.equal(out, st.permute(1, 0, 2).reshape(M, G * n))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        gather = pq.RcclColumnGather()
+        torch.manual_seed(4)
+        lin = torch.nn.Linear(256, 384, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(70, 256, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        y1 = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather)(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        gather.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_swap_linears_on_mlp(pq):
     """Llama-style MLP block (gate/up/down) with every nn.Linear swapped: each projection bit-exact vs the oracle."""
     torch.manual_seed(5)
