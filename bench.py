@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--mode", choices=["dp", "tp"], default="dp")
+    ap.add_argument("--workload", choices=["qlinear", "mlp"], default="qlinear",
+                    help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,8 +88,64 @@ def cpu_baseline(M, N, K):
             "ms_per_step": round(med * 1e3, 2), "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops"}
 
 
+def run_mlp(args):
+    """BASELINE configs[2]: gate/up (horizontally fused, N = 2 x 11008) and down as qlinear at M = 2048; the
+    silu(g)*u in between is stock torch-ROCm elementwise.  One step = the whole block; 554.05 GOP of int8 GEMM."""
+    import protoquant_amd as pq
+    M, H, I = 2048, 4096, 11008
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, H, generator=g).to(torch.bfloat16).to(dev)
+    mk = lambda o, i: pq.qlinear.from_linear(torch.nn.Linear(i, o, bias=False, dtype=torch.bfloat16).to(dev))
+    gate_up = pq.FusedQLinear([mk(I, H), mk(I, H)])
+    down = mk(H, I)
+
+    def block():
+        gt, up = gate_up(x)
+        return down(torch.nn.functional.silu(gt) * up)
+
+    for _ in range(args.warmup):
+        block()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                block()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                block()
+        except Exception as e:
+            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
+            graph = None
+    run = (lambda: graph.replay()) if graph is not None else block
+    for _ in range(20):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops = 2.0 * M * (2 * I) * H + 2.0 * M * H * I
+    print(json.dumps({"metric": "int8 TOPS, Llama MLP block (gate/up/down as qlinear)", "value": round(ops * args.steps / dt / 1e12, 2),
+                      "unit": "TOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+                      "config": {"workload": "Llama MLP block 4096->11008->4096, seq 2048, gate+up fused (BASELINE configs[2])",
+                                 "launch": "hipgraph" if graph is not None else "eager"},
+                      "roofline": {"bound": "mfma", "achieved": round(ops * args.steps / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                                   "frac": round(ops * args.steps / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
+                                   "note": "whole block incl. two quant passes and the torch silu*mul, not a single kernel"},
+                      "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "mlp":
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mlp is a 1-GPU measurement"
+        return run_mlp(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
