@@ -65,7 +65,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int OUT, int SHAPE, int ABL>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
+// TM: rows (m) of the output tile, 256 or 128.  TM = 128 halves the Q (activation) side — 16 rows per wave-half, one
+// 16x16 MFMA tile — for problems whose 256x256 grid would leave most CUs idle; it needs 48 KiB of DMA per
+// 1024 MFMA-cycles, so it runs ingest-bound (~3/4 of the 256-row tile's rate per CU).
+template <int OUT, int SHAPE, int ABL, int TM = 256>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps) {
@@ -91,25 +94,35 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
     const int tin = t - band * GM * tiles_n;
     const int tm = band * GM + tin % gm, tn = tin / gm;
-    const int m0 = tm * FT, n0 = tn * FT;
+    const int m0 = tm * TM, n0 = tn * FT;
 
+    static_assert(TM == 256 || (TM == 128 && SHAPE == 16), "TM = 128 needs the 16x16x64 shape");
+    constexpr int QW = TM / 8;            // Q rows per wave per half-tile: 32 or 16
+    constexpr int QPW = TM / 128;         // DMA pieces per wave per Q half-tile: 2 or 1 (a Q half-tile is TM/2 rows)
     // ---- staging source offsets: wave w issues pieces (w*2+jj), jj = 0,1, of every half-tile.
     // LDS row r = w*16 + jj*8 + (lane>>3) of the half-tile; physical chunk lane&7.
-    // P half h, LDS row r <-> n_local = (r>>6)*128 + h*64 + (r&63);  Q: m_local = (r>>5)*64 + h*32 + (r&31).
-    uint32_t offP[2][2], offQ[2][2];   // [half][jj] byte offset from the tile's first row, k = 0
+    // P half h, LDS row r <-> n_local = (r>>6)*128 + h*64 + (r&63);  Q: m_local = (r/QW)*2QW + h*QW + (r%QW).
+    uint32_t offP[2][2], offQ[2][QPW];   // [half][jj] byte offset from the tile's first row, k = 0
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int r = w * 16 + jj * 8 + (lane >> 3);
             const int src_chunk = (lane & 7) ^ (jj * 4 + (lane >> 4));
             int nl = (r >> 6) * 128 + h * 64 + (r & 63);
-            int ml = (r >> 5) * 64 + h * 32 + (r & 31);
             nl = (n0 + nl < N) ? nl : (N - 1 - n0);       // clamp: rows past the edge re-read a valid row
-            ml = (m0 + ml < M) ? ml : (M - 1 - m0);
             offP[h][jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
+        }
+#pragma unroll
+        for (int jj = 0; jj < QPW; ++jj) {
+            const int piece = w * QPW + jj;               // LDS rows piece*8 .. +7 of the Q half-tile
+            const int r = piece * 8 + (lane >> 3);
+            const int src_chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+            int ml = (r / QW) * (2 * QW) + h * QW + (r % QW);
+            ml = (m0 + ml < M) ? ml : (M - 1 - m0);
             offQ[h][jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
         }
+    }
     const int8_t* gP = W + (int64_t)n0 * ldw;   // uniform; advanced by FBK per staged K-tile
     const int8_t* gQ = X + (int64_t)m0 * ldx;
     const int piece_off = w * 2048;             // pieces w*2 and w*2+1 of a half-tile
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     // ---- fragment read addresses (lane part)
     constexpr int NPI = (SHAPE == 16) ? 4 : 2;     // P tiles per half (64 rows)
-    constexpr int NQJ = (SHAPE == 16) ? 2 : 1;     // Q tiles per half (32 rows)
+    constexpr int NQJ = (SHAPE == 16) ? QW / 16 : 1;   // Q tiles per wave-half (QW rows)
     constexpr int NKS = (SHAPE == 16) ? 2 : 4;     // MFMA k-steps per 128-byte row
     constexpr int NACC = (SHAPE == 16) ? 4 : 16;   // accumulator registers per tile
     const int frow = (SHAPE == 16) ? (lane & 15) : (lane & 31);
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     for (int ks = 0; ks < NKS; ++ks) {
         const int c = ks * (8 / NKS) + fchunk;
         lP[ks] = (uint32_t)((wp * 64 + frow) * 128 + ((c ^ fkey) * 16));
-        lQ[ks] = (uint32_t)((wq * 32 + frow) * 128 + ((c ^ fkey) * 16)) + 2 * HALF_BYTES;
+        lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * HALF_BYTES;
     }
 
     using acc_t = typename std::conditional<SHAPE == 16, v4i, v16i>::type;
@@ -157,20 +170,30 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     }
 
     // ---- issue items.  Everything below is hand-interleaved: ONE item in the shadow of each MFMA.
-    // DMA piece g (0..7) of a K-tile, in need order P0a P0b Q0a Q0b Q1a Q1b P1a P1b
+    // DMA piece g of a K-tile, in need order P0a P0b | Q0 (QPW pieces) | Q1 (QPW pieces) | P1a P1b
+    constexpr int NDMA = 4 + 2 * QPW;
     auto dma_item = [&](int buf, auto gc) {
         constexpr int g = decltype(gc)::value;
-        constexpr int isQ = (g >= 2 && g < 6), h = (g >= 4), jj = g & 1;
-        if (!no_dma) {
-            const uint32_t la = smem_base + buf * BUF_BYTES + piece_off + isQ * 2 * HALF_BYTES + h * HALF_BYTES + jj * 1024;
-            glds16_sbase(isQ ? gQ : gP, isQ ? offQ[h][jj] : offP[h][jj], la);
+        if constexpr (g < NDMA) {
+            constexpr bool isQ = (g >= 2 && g < 2 + 2 * QPW);
+            constexpr int h = isQ ? (g - 2) / QPW : (g >= 2 ? 1 : 0);
+            constexpr int jj = isQ ? (g - 2) % QPW : (g & 1);
+            if (!no_dma) {
+                if constexpr (isQ) {
+                    const uint32_t la = smem_base + buf * BUF_BYTES + 2 * HALF_BYTES + h * HALF_BYTES + (w * QPW + jj) * 1024;
+                    glds16_sbase(gQ, offQ[h][jj], la);
+                } else {
+                    const uint32_t la = smem_base + buf * BUF_BYTES + h * HALF_BYTES + piece_off + jj * 1024;
+                    glds16_sbase(gP, offP[h][jj], la);
+                }
+            }
+            if constexpr (g == NDMA - 1) { gP += FBK; gQ += FBK; }
         }
-        if constexpr (g == 7) { gP += FBK; gQ += FBK; }
     };
     auto stage_tile = [&](int buf) {   // whole tile at once (prologue only)
-        static_for<8>([&](auto gc) { dma_item(buf, gc); });
+        static_for<NDMA>([&](auto gc) { dma_item(buf, gc); });
     };
-    // fragment item it: P: i = it % NPI, ks = it / NPI (8 items); Q: j = it % NQJ, ks = it / NQJ (4 items)
+    // fragment item it: P: i = it % NPI, ks = it / NPI (8 items); Q: j = it % NQJ, ks = it / NQJ (NQR items)
     auto readP_item = [&](int bufoff, int h, v4i (&f)[NPI][NKS], auto ic) {
         constexpr int it = decltype(ic)::value, i = it % NPI, ks = it / NPI;
         if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * HALF_BYTES + i * SHAPE * 128);
@@ -180,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * HALF_BYTES + j * SHAPE * 128);
     };
     auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<8>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
-    auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) { static_for<4>([&](auto ic) { readQ_item(bufoff, h, f, ic); }); };
+    constexpr int NQR = NQJ * NKS;               // Q fragment reads per half: 4 or 2
+    auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) { static_for<NQR>([&](auto ic) { readQ_item(bufoff, h, f, ic); }); };
 
     constexpr int NM = NKS * NPI * NQJ;          // MFMAs per quadrant: 16 or 8
     constexpr int PPS = 8 / (NM / 2);            // P reads (or DMA pieces) per slot: 1 or 2
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value;
         mma(acc[0][0], fPa, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (x < 4) readQ_item(bufoff, 1, fQb, xc);
+            if constexpr (x < NQR) readQ_item(bufoff, 1, fQb, xc);
         });
         mma(acc[0][1], fPa, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         });
         mma(acc[1][1], fPb, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < 4) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
+            if constexpr (next && x < NQR) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
         });
     };
     constexpr std::true_type yes{};
@@ -253,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         }
     }
     stage_tile(0);
-    if (NT > 1) { stage_tile(1); __builtin_amdgcn_s_waitcnt(0x0078); }   // vmcnt(8) lgkmcnt(0)
+    if (NT > 1) { stage_tile(1); if constexpr (NDMA == 8) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0076); }   // vmcnt(NDMA) lgkmcnt(0)
     else { __builtin_amdgcn_s_waitcnt(0x0070); }                          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     readP(0, 0, fPa);
@@ -294,10 +318,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int dcol = (SHAPE == 16) ? (lane & 15) : (lane & 31);            // m inside a Q tile
     const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // first of 4 consecutive n (+8g for 32x32)
     constexpr int NG = (SHAPE == 16) ? 1 : 4;
-    const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 128;                      // this wave's 64(m) x 128(n) block
+    constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
+    const int wm0 = m0 + wq * WM, wn0 = n0 + wp * 128;                      // this wave's WM(m) x 128(n) block
 
     // staged path: whole block in range, 16-byte aligned rows
-    const bool staged = !direct_epi && scales_in_lds && (wm0 + 64 <= M) && (wn0 + 128 <= N) &&
+    const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + 128 <= N) &&
                         ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
     __builtin_amdgcn_s_barrier();     // every wave is done reading the K-loop buffers (uniform: all waves reach it)
     if (staged) {
@@ -309,9 +334,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             for (int hQ = 0; hQ < 2; ++hQ)
 #pragma unroll
                 for (int j = 0; j < NQJ; ++j) {
-                    const int ml = hQ * 32 + j * SHAPE + dcol;
+                    const int ml = hQ * QW + j * SHAPE + dcol;
                     float as = 1.0f;
-                    if constexpr (OUT != OUT_I32 && !const_scale) as = reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * 64 + ml];
+                    if constexpr (OUT != OUT_I32 && !const_scale) as = reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * WM + ml];
 #pragma unroll
                     for (int hP = 0; hP < 2; ++hP) {
                         if (NPASS == 2 && hP != pass) continue;
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             // wave-private region: only this wave's LDS writes must retire before its reads (no barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
+            for (int it = 0; it < WM / 4; ++it) {
                 const int r = it * 4 + (lane >> 4), ch = lane & 15;
                 const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ((ch ^ (r & 15)) << 4));
                 uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
@@ -362,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     for (int hQ = 0; hQ < 2; ++hQ)
 #pragma unroll
         for (int j = 0; j < NQJ; ++j) {
-            const int m = wm0 + hQ * 32 + j * SHAPE + dcol;
+            const int m = wm0 + hQ * QW + j * SHAPE + dcol;
             const bool mok = m < M;
             float as = 1.0f;
             if constexpr (OUT != OUT_I32) as = mok ? epi.a_scale[m] : 0.0f;
@@ -415,13 +440,13 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
-template <int OUT, int SHAPE>
+template <int OUT, int SHAPE, int TM>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
                       int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    const int tiles_m = (int)((M + FT - 1) / FT), tiles_n = (int)((N + FT - 1) / FT);
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
 #ifdef PQ_ABLATION_BUILD
-    if constexpr (OUT == PQ_BF16 && SHAPE == 16) {
+    if constexpr (OUT == PQ_BF16 && SHAPE == 16 && TM == 256) {
         switch (gemm_debug_flags()) {
 #define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps); return;
             PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(128) PQ_ABL(256) PQ_ABL(384) PQ_ABL(1024)
@@ -430,13 +455,14 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         }
     }
 #endif
-    gemm_s8_sp256<OUT, SHAPE, 0><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr);
+    gemm_s8_sp256<OUT, SHAPE, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr);
 }
 
-#define PQ_INST(OUT, SHAPE) \
-    template void launch_gemm_fast<OUT, SHAPE>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-PQ_INST(PQ_BF16, 16) PQ_INST(PQ_FP16, 16) PQ_INST(PQ_F32, 16) PQ_INST(OUT_I32, 16)
-PQ_INST(PQ_BF16, 32) PQ_INST(OUT_I32, 32)
+#define PQ_INST(OUT, SHAPE, TM) \
+    template void launch_gemm_fast<OUT, SHAPE, TM>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+PQ_INST(PQ_BF16, 16, 256) PQ_INST(PQ_FP16, 16, 256) PQ_INST(PQ_F32, 16, 256) PQ_INST(OUT_I32, 16, 256)
+PQ_INST(PQ_BF16, 16, 128) PQ_INST(PQ_FP16, 16, 128) PQ_INST(PQ_F32, 16, 128) PQ_INST(OUT_I32, 16, 128)
+PQ_INST(PQ_BF16, 32, 256) PQ_INST(OUT_I32, 32, 256)
 #undef PQ_INST
 
 }  // namespace pq

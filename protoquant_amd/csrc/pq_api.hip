@@ -12,7 +12,7 @@ template <int DT> void quant_rowwise_dispatch(const void*, int64_t, int64_t, int
 template <int DT> void quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template <int OUT, int SHAPE> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT, int SHAPE, int TM> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 void set_stamp_buffer(unsigned long long*);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
@@ -36,7 +36,7 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32 };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16 };
 
 Variant forced_variant() {
     const char* e = getenv("PQ_FORCE_VARIANT");
@@ -44,6 +44,7 @@ Variant forced_variant() {
     if (!strcmp(e, "generic")) return V_GENERIC;
     if (!strcmp(e, "sp256_16")) return V_SP256_16;
     if (!strcmp(e, "sp256_32")) return V_SP256_32;
+    if (!strcmp(e, "sp128_16")) return V_SP128_16;
     return V_AUTO;
 }
 
@@ -53,16 +54,21 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     if (f == V_GENERIC || !ok) return V_GENERIC;
     if (f != V_AUTO) return f;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
+    // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
+    // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
+    if (t256 <= 160 && t128 > t256 && t128 <= 256) return V_SP128_16;
     return V_SP256_16;
 }
 
 template <int OUT>
 void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
               int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
+    if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 16, 256>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_SP128_16) pq::launch_gemm_fast<OUT, 16, 128>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP256_32) {
-        if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32>(a, lda, b, ldb, epi, M, N, K, st);
-        else pq::launch_gemm_fast<OUT, 16>(a, lda, b, ldb, epi, M, N, K, st);
+        if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32, 256>(a, lda, b, ldb, epi, M, N, K, st);
+        else pq::launch_gemm_fast<OUT, 16, 256>(a, lda, b, ldb, epi, M, N, K, st);
     } else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
 }
 
@@ -170,6 +176,7 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
     switch (pick_variant(reinterpret_cast<const int8_t*>(16), lda, reinterpret_cast<const int8_t*>(16), ldb, M, N, K)) {
         case V_SP256_16: return "sp256_16x16x64";
         case V_SP256_32: return "sp256_32x32x32";
+        case V_SP128_16: return "sp128x256_16x16x64";
         default: return "generic64";
     }
 }
