@@ -411,6 +411,20 @@ def test_randomized_shape_sweep(pq):
         same(y, y_want, tag + " y")
 
 
+def test_qlinear_state_dict_roundtrip(pq):
+    """The pre-quantised weight (wq int8, ws f32, bias) is plain module state: save -> load -> identical outputs."""
+    import io
+    torch.manual_seed(12)
+    lin = torch.nn.Linear(384, 256, bias=True, device="cuda", dtype=torch.bfloat16)
+    m = pq.qlinear.from_linear(lin)
+    buf = io.BytesIO(); torch.save(m.state_dict(), buf); buf.seek(0)
+    m2 = pq.qlinear(384, 256, bias=True, device="cuda", dtype=torch.bfloat16)
+    m2.load_state_dict(torch.load(buf))
+    x = torch.randn(33, 384, device="cuda", dtype=torch.bfloat16)
+    assert torch.equal(m(x).view(torch.int16), m2(x).view(torch.int16))
+    assert sorted(m.state_dict()) == ["bias", "wq", "ws"]
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):

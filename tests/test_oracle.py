@@ -93,3 +93,29 @@ def test_quant_properties():
             assert np.all(err <= s[:, None] * 0.5 * (1 + 1e-6))
             qc, sc = C.quant_rowwise(x, 2)
             eq(q, qc); eq(s, sc)
+
+
+# ---- hypothesis property tests: scale > 0, |q| <= 127, round-trip error <= scale/2, zero rows
+from hypothesis import given, settings, strategies as st  # noqa: E402
+from hypothesis.extra import numpy as hnp  # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(hnp.arrays(np.float32, hnp.array_shapes(min_dims=2, max_dims=2, min_side=1, max_side=24),
+                  elements=st.floats(-1e4, 1e4, width=32, allow_nan=False, allow_infinity=False)),
+       st.sampled_from([0, 1, 2]))
+def test_quantize_properties_hypothesis(xf, dtype):
+    x = Q.from_f32(xf, dtype)
+    xr = Q.to_f32(x, dtype)
+    for axis, cfn in ((1, C.quant_rowwise), (0, C.quant_colwise)):
+        q, s = Q.quantize(x, dtype, axis)
+        qc, sc = cfn(x, dtype)
+        eq(q, qc); eq(s, sc)
+        assert np.all(s > 0) and np.all(np.isfinite(s) | ~np.isfinite(xr).all())
+        assert np.abs(q.astype(np.int32)).max() <= 127
+        finite = np.isfinite(xr).all()
+        if finite:
+            se = np.expand_dims(s, axis)
+            assert np.all(np.abs(xr - q.astype(np.float32) * se) <= se * 0.5 * (1 + 1e-6) + 1e-30)
+            zero = (np.abs(xr).max(axis=axis) == 0)
+            assert np.all(s[zero] == 1.0)
