@@ -356,8 +356,22 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                                     }
                                 }
                                 O o[4];
+                                if constexpr (OUT == OUT_I32) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs[r], bf[r], has_bias);
+                                    for (int r = 0; r < 4; ++r) o[r] = c[g * 4 + r];
+                                } else {
+                                    // E1-E4 on 2-wide vectors: v_pk_mul_f32 / v_pk_add_f32 (each lane-op still rounds separately)
+                                    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+                                    for (int r = 0; r < 4; r += 2) {
+                                        v2f t = {(float)c[g * 4 + r], (float)c[g * 4 + r + 1]};
+                                        t = t * v2f{as, as};
+                                        t = t * v2f{bs[r], bs[r + 1]};
+                                        if (has_bias) t = t + v2f{bf[r], bf[r + 1]};
+                                        o[r] = Elem<OUT>::from_f32(t[0]);
+                                        o[r + 1] = Elem<OUT>::from_f32(t[1]);
+                                    }
+                                }
                                 const int ncol = (NPASS == 2) ? (nl - pass * 64) : nl;
                                 const int boff = ncol * OB;                              // byte offset inside the 256-B row
                                 uint8_t* d = sw + ml * EPI_ROW + ((((boff >> 4) ^ (ml & 15)) << 4) | (boff & 15));
