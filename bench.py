@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--mode", choices=["dp", "tp"], default="dp")
-    ap.add_argument("--workload", choices=["qlinear", "mlp"], default="qlinear",
-                    help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048")
+    ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b"], default="qlinear",
+                    help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,8 +141,58 @@ def run_mlp(args):
                       "cpu_baseline": None}), flush=True)
 
 
+def run_llama8b(args):
+    """BASELINE configs[3], linears only: 32 layers x {fused qkv 4096->6144, o 4096->4096, fused gate+up 4096->28672,
+    down 14336->4096} + lm_head 4096->128256 at M = 4096 tokens (bs 1, seq 4096): 61.48 TOP of int8 GEMM per pass.
+    Synthetic int8 weights (gaussian codes) and scales; every activation quantisation (K1) is included; attention,
+    norms and rope are NOT run (the o-projection input is a slice of the qkv output, the down input is silu(g)*u)."""
+    import protoquant_amd as pq
+    from protoquant_amd.qtensor import QTensor
+    dev = torch.device("cuda", 0)
+    M, H, I, V, L = 4096, 4096, 14336, 128256, 32
+
+    def mkq(n, k):
+        wq = (torch.randn(n, k, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
+        return pq.qlinear.from_qtensor(QTensor(wq, torch.rand(n, device=dev) * 1e-3 + 1e-4, 1, torch.bfloat16, wq.shape))
+
+    layers = [(mkq(6144, H), mkq(H, H), mkq(2 * I, H), mkq(H, I)) for _ in range(L)]
+    head = mkq(V, H)
+    x0 = torch.randn(M, H, device=dev).to(torch.bfloat16)
+
+    def fwd():
+        x = x0
+        for qkv, o, gu, down in layers:
+            a = qkv(x)[:, :H].contiguous()
+            x = o(a)
+            g_u = gu(x)
+            x = down(torch.nn.functional.silu(g_u[:, :I]) * g_u[:, I:])
+        return head(x)
+
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ops = L * (2.0 * M * 6144 * H + 2.0 * M * H * H + 2.0 * M * 2 * I * H + 2.0 * M * H * I) + 2.0 * M * V * H
+    print(json.dumps({"metric": "int8 TOPS, Llama-3-8B linears at prefill seq 4096", "value": round(ops / dt / 1e12, 2), "unit": "TOPS",
+                      "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+                      "config": {"workload": "Llama-3-8B every linear as qlinear (qkv and gate/up fused), bs 1 seq 4096, linears + quant passes only (BASELINE configs[3])",
+                                 "launch": "eager", "int8_ops_per_step": ops},
+                      "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                                   "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
+                                   "note": "whole pass incl. quant passes and torch elementwise glue"},
+                      "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "llama8b":
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"
+        return run_llama8b(args)
     if args.workload == "mlp":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mlp is a 1-GPU measurement"
         return run_mlp(args)
