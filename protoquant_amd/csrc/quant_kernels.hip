@@ -262,9 +262,9 @@ __global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, i
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t cvr = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cvr = (int64_t)blockIdx.y * 64 + lane;          // rows ride on grid.x (2^31 blocks), columns on grid.y
     const int64_t cv = cvr < ncolv ? cvr : ncolv - 1;            // clamped: duplicates do not change a max
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float m[EPV];
 #pragma unroll
@@ -306,10 +306,10 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t cvr = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cvr = (int64_t)blockIdx.y * 64 + lane;
     const bool live = cvr < ncolv;
     const int64_t cv = live ? cvr : ncolv - 1;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s[EPV], rcp[EPV];
     bool ok = true;
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
                                                       int64_t ncolv, void* __restrict__ out, int64_t ldo) {
     using S = typename Elem<ODT>::store_t;
     constexpr int EPT = VEC ? 16 / (int)sizeof(S) : 1;      // 8 (half) or 4 (f32) codes per thread
-    const int64_t cvr = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int64_t cvr = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);   // rows ride on grid.x (2^31 blocks)
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cvr >= ncolv || r >= rows) return;
     const int8_t* p = q + r * ldq + cvr * EPT;
     S* o = reinterpret_cast<S*>(out) + r * ldo + cvr * EPT;
@@ -449,7 +449,7 @@ void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
     const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) && aligned(q, EPV);
     const int64_t ncolv = vec_ok ? cols / EPV : cols;
     const int rpb = 64;
-    const dim3 grid((unsigned)((ncolv + 63) / 64), (unsigned)((rows + rpb - 1) / rpb)), block(256);
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((ncolv + 63) / 64)), block(256);
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const int64_t ldb = ldx * Elem<DT>::kBytes;
     (void)hipMemsetAsync(scale, 0, (size_t)cols * sizeof(float), st);
@@ -472,7 +472,7 @@ void dequant_dispatch(const int8_t* q, int64_t ldq, const float* scale, int axis
     const bool vec_ok = (cols % EPT == 0) && (ldq % EPT == 0) && aligned(q, EPT) && aligned(out, 16) &&
                         ((ldo * Elem<ODT>::kBytes) % 16 == 0) && (axis != 0 || aligned(scale, 16));
     const int64_t ncolv = vec_ok ? cols / EPT : cols;
-    const dim3 grid((unsigned)((ncolv + 63) / 64), (unsigned)((rows + 3) / 4)), block(256);
+    const dim3 grid((unsigned)((rows + 3) / 4), (unsigned)((ncolv + 63) / 64)), block(256);
     if (vec_ok) dequant_kernel<ODT, true><<<grid, block, 0, st>>>(q, ldq, scale, axis, rows, ncolv, out, ldo);
     else dequant_kernel<ODT, false><<<grid, block, 0, st>>>(q, ldq, scale, axis, rows, ncolv, out, ldo);
 }

@@ -135,6 +135,20 @@ def test_quant_special_values(pq, code):
     same(qc.int_data, cq, "col codes"); same(qc.scale, cs, "col scale")
 
 
+def test_many_rows_dequant_and_colquant(pq):
+    """More than 65 535 x 4 rows: row blocks ride on grid.x (a grid.y of that size would fail to launch)."""
+    rows, cols = 300000, 16
+    x = (torch.randn(rows, cols, device="cuda") * 3).to(torch.bfloat16)
+    xb = bits(x)
+    q = pq.quantize(x, axis=-1)
+    wq, ws = C.quant_rowwise(xb, 0)
+    same(q.int_data, wq, "rows>262k codes"); same(q.scale, ws, "rows>262k scale")
+    same(pq.dequantize(q), C.dequant(wq, ws, 1, 0), "rows>262k dequant")
+    qc = pq.quantize(x, axis=0)
+    cq, cs = C.quant_colwise(xb, 0)
+    same(qc.int_data, cq, "rows>262k col codes"); same(qc.scale, cs, "rows>262k col scale")
+
+
 def test_quant_strided_and_unaligned(pq):
     """Leading dimension > cols and an odd element offset take the generic paths."""
     rng = np.random.default_rng(11)
