@@ -69,8 +69,10 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
 
 /* K3+K4 — int8 GEMM on v_mfma_i32_*_i8 with the fused dequant epilogue:
  *   y[m,n] = cast_rne_out((f32(acc[m,n]) * a_scale[m]) * b_scale[n] (+ f32(bias[n])))   QSPEC E1-E4.
- * bias is nullable and has the output dtype.  workspace may be NULL when
- * pq_qlinear_workspace_bytes(M,N,K) == 0 (always, in this version). */
+ * bias is nullable and has the output dtype.
+ * workspace: optional.  pq_qlinear_workspace_bytes(M,N,K) > 0 marks problems (small M*N, long K) for which a
+ * 16-byte aligned device workspace of that size enables split-K (partial int32 slabs + an exact integer reduction:
+ * results are bit-identical); with workspace == NULL the single-pass kernel runs instead. */
 int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       const int8_t* b, int64_t ldb, const float* b_scale,
                       const void* bias, void* y, int64_t ldy, int32_t out_dtype,

@@ -71,7 +71,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int OUT, int SHAPE, int ABL, int TM = 256>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
-                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps) {
+                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
     // ablation bits (dev builds only): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue, 16 direct epilogue
     constexpr bool DBG = ABL != 0;
     constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
@@ -88,7 +88,12 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int wp = w >> 2, wq = w & 3;
 
     // ---- tile assignment: XCD remap, then grouped order (GM m-tiles per band) for L2 reuse
-    int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // split-K (int32 output only): blocks [s*ntiles, (s+1)*ntiles) own K-slice s and write their exact partial
+    // accumulators to slab s of the output buffer; a separate kernel sums the slabs and applies the epilogue.
+    const int ntiles_all = tiles_m * tiles_n;
+    const int kslice = (int)blockIdx.x / ntiles_all;
+    const int Ks = K / kslices;                       // bytes of K per slice (a multiple of FBK)
+    int t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all);
     constexpr int GM = 4;
     const int band = t / (GM * tiles_n);
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             offQ[h][jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
         }
     }
-    const int8_t* gP = W + (int64_t)n0 * ldw;   // uniform; advanced by FBK per staged K-tile
-    const int8_t* gQ = X + (int64_t)m0 * ldx;
+    const int8_t* gP = W + (int64_t)n0 * ldw + (int64_t)kslice * Ks;   // uniform; advanced by FBK per staged K-tile
+    const int8_t* gQ = X + (int64_t)m0 * ldx + (int64_t)kslice * Ks;
     const int piece_off = w * 2048;             // pieces w*2 and w*2+1 of a half-tile
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;   // LDS byte address of the array
 
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         });
     };
 
-    const int NT = K / FBK;
+    const int NT = Ks / FBK;
 
     // One K-tile, branch-free inside (flags are compile-time).  Quadrant order (P0,Q0) (P0,Q1) (P1,Q0)
     // (P1,Q1): every register set returns to the same role each tile.  Entry: fPa = P0[kt], fQa = Q0[kt].
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     using O = typename OutElem<OUT>::type;
     constexpr int OB = (int)sizeof(O);
-    O* y = reinterpret_cast<O*>(epi.y);
+    O* y = reinterpret_cast<O*>(epi.y) + (int64_t)kslice * M * epi.ldy;   // slab of this K-slice (kslices == 1: the output itself)
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     const int dcol = (SHAPE == 16) ? (lane & 15) : (lane & 31);            // m inside a Q tile
     const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // first of 4 consecutive n (+8g for 32x32)
@@ -462,15 +467,71 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && SHAPE == 16 && TM == 256) {
         switch (gemm_debug_flags()) {
-#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps); return;
+#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
             PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(128) PQ_ABL(256) PQ_ABL(384) PQ_ABL(1024)
 #undef PQ_ABL
             default: break;
         }
     }
 #endif
-    gemm_s8_sp256<OUT, SHAPE, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr);
+    gemm_s8_sp256<OUT, SHAPE, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
 }
+
+// ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
+// the slabs (exact) and applies QSPEC E1-E4.  Doubles/quadruples the busy CUs for small-MN / long-K problems.
+template <int TM>
+void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, int32_t* slabs,
+                            int64_t M, int64_t N, int64_t K, int kslices, hipStream_t st) {
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
+    const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
+    EpiArgs epi{nullptr, nullptr, nullptr, slabs, N};
+    gemm_s8_sp256<OUT_I32, 16, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
+}
+template void launch_gemm_splitk_i32<256>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
+template void launch_gemm_splitk_i32<128>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
+
+template <int OUT>
+__global__ __launch_bounds__(256) void splitk_reduce_epilogue(const int32_t* __restrict__ slabs, int kslices, int64_t M, int64_t N,
+                                                              EpiArgs epi) {
+    using O = typename OutElem<OUT>::type;
+    const int64_t nvec = (N + 3) / 4;                                  // 4 consecutive n per thread
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nvec) return;
+    const int64_t m = i / nvec, n = (i % nvec) * 4;
+    const bool full = (n + 3 < N) && ((N & 3) == 0);
+    int acc[4] = {0, 0, 0, 0};
+    for (int s = 0; s < kslices; ++s) {
+        const int32_t* p = slabs + ((int64_t)s * M + m) * N + n;
+        if (full) { const v4i v = *reinterpret_cast<const v4i*>(p); acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+        else { for (int r = 0; r < 4; ++r) if (n + r < N) acc[r] += p[r]; }
+    }
+    const float as = epi.a_scale[m];
+    const bool has_bias = epi.bias != nullptr;
+    O* dst = reinterpret_cast<O*>(epi.y) + m * epi.ldy + n;
+    O o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (n + r < N) {
+            const float bf = has_bias ? load_bias<OUT>(epi.bias, n + r) : 0.0f;
+            o[r] = epi_convert<OUT>(acc[r], as, epi.b_scale[n + r], bf, has_bias);
+        } else o[r] = O{};
+    }
+    const bool vec_st = full && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
+    if (vec_st) {
+        if constexpr (sizeof(O) == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+        else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+    } else {
+        for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = o[r];
+    }
+}
+template <int OUT>
+void launch_splitk_reduce(const int32_t* slabs, int kslices, int64_t M, int64_t N, const EpiArgs& epi, hipStream_t st) {
+    const int64_t work = M * ((N + 3) / 4);
+    splitk_reduce_epilogue<OUT><<<dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st>>>(slabs, kslices, M, N, epi);
+}
+template void launch_splitk_reduce<PQ_BF16>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
+template void launch_splitk_reduce<PQ_FP16>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
+template void launch_splitk_reduce<PQ_F32>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 
 #define PQ_INST(OUT, SHAPE, TM) \
     template void launch_gemm_fast<OUT, SHAPE, TM>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

@@ -14,6 +14,8 @@ template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, i
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE, int TM> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
+template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
+template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 void set_stamp_buffer(unsigned long long*);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
@@ -139,12 +141,31 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
     return check_launch("pq_gemm_s8s8s32");
 }
 
-size_t pq_qlinear_workspace_bytes(int64_t, int64_t, int64_t) { return 0; }
+// split-K plan: how many K-slices (1 = none) and which tile height.  Only when the tile grid fills at most half of the
+// 256 CUs even with 128-row tiles, K is long enough to amortise the extra pass, and the slices stay multiples of 128.
+static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
+    if (getenv("PQ_NO_SPLITK")) return 1;
+    if (M < 1 || N < 1 || K < 2048) return 1;
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
+    const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
+    const int64_t tiles = tm == 128 ? t128 : t256;
+    if (tiles > 128) return 1;
+    int s = tiles <= 64 ? 4 : 2;
+    while (s > 1 && (K % (128 * s) != 0 || K / s < 1024)) s >>= 1;
+    if (s == 2 && K < 8192) s = 1;     // the slab reduction costs ~15 us: two slices only pay on long K (measured)
+    *tm_out = tm;
+    return s;
+}
+
+size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    int tm = 256;
+    const int s = splitk_plan(M, N, K, &tm);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(int32_t) : 0;
+}
 
 int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
                       const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M,
                       int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
     if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: unknown dtype %d", out_dtype);
     if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(y, M, N, ldy) ||
         (M > 0 && !a_scale) || (N > 0 && !b_scale))
@@ -153,6 +174,23 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
     pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy};
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.
+    int tm = 256;
+    const int ks = (v == V_SP256_16 || v == V_SP128_16) && forced_variant() == V_AUTO ? splitk_plan(M, N, K, &tm) : 1;
+    if (ks > 1 && workspace != nullptr) {
+        const size_t need = (size_t)ks * (size_t)M * (size_t)N * sizeof(int32_t);
+        if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8: workspace %zu < %zu bytes", workspace_bytes, need);
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "pq_qlinear_s8: workspace must be 16-byte aligned");
+        int32_t* slabs = static_cast<int32_t*>(workspace);
+        if (tm == 128) pq::launch_gemm_splitk_i32<128>(a, lda, b, ldb, slabs, M, N, K, ks, st);
+        else pq::launch_gemm_splitk_i32<256>(a, lda, b, ldb, slabs, M, N, K, ks, st);
+        switch (out_dtype) {
+            case PQ_BF16: pq::launch_splitk_reduce<PQ_BF16>(slabs, ks, M, N, epi, st); break;
+            case PQ_FP16: pq::launch_splitk_reduce<PQ_FP16>(slabs, ks, M, N, epi, st); break;
+            default: pq::launch_splitk_reduce<PQ_F32>(slabs, ks, M, N, epi, st); break;
+        }
+        return check_launch("pq_qlinear_s8 (split-K)");
+    }
     switch (out_dtype) {
         case PQ_BF16: run_gemm<PQ_BF16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
         case PQ_FP16: run_gemm<PQ_FP16>(v, a, lda, b, ldb, epi, M, N, K, st); break;

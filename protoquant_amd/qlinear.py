@@ -28,6 +28,19 @@ def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
     return acc
 
 
+_WORKSPACES: dict = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Caller-owned split-K workspace, one growing buffer per device (stream-ordered reuse on the current stream)."""
+    key = (device.type, device.index)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
 def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
                out: torch.Tensor | None = None) -> torch.Tensor:
     """Fused int8 GEMM + dequant epilogue on pre-quantised operands (C-ABI pq_qlinear_s8)."""
@@ -41,10 +54,13 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
     if bias is not None and bias.dtype != out_dtype:
         bias = bias.to(out_dtype)
     y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    wbytes = L.lib().pq_qlinear_workspace_bytes(M, N, K)        # > 0: split-K pays for this shape
+    wsp = _workspace(xq.device, wbytes) if wbytes else None
     with torch.cuda.device(xq.device):
         L.check(L.lib().pq_qlinear_s8(xq.data_ptr(), L.ld(xq), xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), L.ld(y), code,
-                                      M, N, K, None, 0, L.stream_ptr(xq)), "qlinear_s8")
+                                      M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes,
+                                      L.stream_ptr(xq)), "qlinear_s8")
     return y
 
 

@@ -201,6 +201,44 @@ def test_qlinear_unaligned_scales_and_output(pq):
     same(out.contiguous(), want, "unaligned output")
 
 
+@pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 4096, 0, True), (512, 1024, 4096, 0, False), (130, 517, 4096, 2, True),
+                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False)])
+def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
+    """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
+    == the single-pass kernel (PQ_NO_SPLITK)."""
+    from protoquant_amd import _lib
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0, "shape should be planned as split-K"
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
+    want = Q.epilogue((a.astype(np.int64) @ b.astype(np.int64).T).astype(np.int32), xs, ws, bv, code)
+    args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
+            to_gpu(bv, code) if bias else None, TD[code])
+    same(pq.qlinear_s8(*args), want, "split-K y")
+    monkeypatch.setenv("PQ_NO_SPLITK", "1")
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0
+    same(pq.qlinear_s8(*args), want, "single-pass y")
+
+
+def test_splitk_workspace_too_small_is_an_error(pq):
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    M, N, K = 512, 1024, 4096
+    need = L.pq_qlinear_workspace_bytes(M, N, K)
+    assert need > 0
+    a = torch.zeros((M, K), dtype=torch.int8, device="cuda"); b = torch.zeros((N, K), dtype=torch.int8, device="cuda")
+    s1 = torch.ones(M, device="cuda"); s2 = torch.ones(N, device="cuda"); y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    wsp = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    st = L.pq_qlinear_s8(a.data_ptr(), K, s1.data_ptr(), b.data_ptr(), K, s2.data_ptr(), None, y.data_ptr(), N, 0, M, N, K,
+                         wsp.data_ptr(), wsp.numel(), None)
+    assert st == 5 and b"workspace" in L.pq_last_error()
+    # NULL workspace: allowed, single-pass path
+    st = L.pq_qlinear_s8(a.data_ptr(), K, s1.data_ptr(), b.data_ptr(), K, s2.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, None, 0, None)
+    torch.cuda.synchronize()
+    assert st == 0 and float(y.float().abs().max()) == 0.0
+
+
 def test_full_size_cfg2_properties(pq):
     """BASELINE config 2 (M=N=K=4096, bf16): size-independent checks + sampled exact parity.
     (a) xq/xs bit-exact vs the C oracle on all rows; (b) int32 accumulator exact vs int64 matmul on

@@ -25,9 +25,11 @@ for M, N, K, name in SHAPES:
     wq = (torch.randn(N, K, device="cuda") * 28).round().clamp(-127, 127).to(torch.int8)
     xs = torch.rand(M, device="cuda"); ws = torch.rand(N, device="cuda"); y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    f = lambda: lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, None, 0, st)
+    wb = lib.pq_qlinear_workspace_bytes(M, N, K)
+    wsp = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
+    f = lambda: lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, wsp.data_ptr() if wb else None, wb, st)
     ops = 2.0 * M * N * K
     us = t(f, 30 if ops > 1e12 else 100)
     tiles = -(-M // 256) * -(-N // 256)
-    print(f"{name:22s} {M:5d} x {N:6d} x {K:5d}  tiles {tiles:5d} ({tiles/256:5.2f} waves)  {us:9.1f} us  {ops/us/1e6:7.1f} TOPS  {ops/us/1e6/50.33:5.1f} %  [{lib.pq_gemm_variant_name(M,N,K,K,K).decode()}]")
+    print(f"{name:22s} {M:5d} x {N:6d} x {K:5d}  tiles {tiles:5d} ({tiles/256:5.2f} waves)  {us:9.1f} us  {ops/us/1e6:7.1f} TOPS  {ops/us/1e6/50.33:5.1f} %  [{lib.pq_gemm_variant_name(M,N,K,K,K).decode()}{' + split-K' if wb else ''}]")
     del xq, wq, y
