@@ -239,9 +239,12 @@ def main():
         L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream), "pq_quant_rowwise")
 
+    wbytes = lib.pq_qlinear_workspace_bytes(M, n_local, K)        # 0 for the headline shape; > 0 for narrow tp shards (split-K)
+    wsp = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+
     def k3():
         L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
-                                  y.data_ptr(), n_local, 0, M, n_local, K, None, 0,
+                                  y.data_ptr(), n_local, 0, M, n_local, K, wsp.data_ptr() if wbytes else None, wbytes,
                                   torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
 
     def step_eager():

@@ -1,0 +1,26 @@
+"""Dev tool: repeat the GEMM many times per shape under load and compare every result bitwise (race screen)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import protoquant_amd as pq
+SHAPES = [(4096, 4096, 4096, 300), (4096, 1024, 8192, 300), (2048, 4096, 11008, 200), (1000, 3000, 1024, 400), (257, 511, 256, 800),
+          (512, 4096, 4096, 400), (8192, 8192, 1024, 100), (4096, 4096, 128, 500), (4096, 4096, 256, 500)]
+bad_total = 0
+for M, N, K, reps in SHAPES:
+    torch.manual_seed(M + N + K)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda"); b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda")
+    xs = torch.rand(M, device="cuda"); ws = torch.rand(N, device="cuda")
+    ref_acc = pq.int_mm(a, b).clone()
+    rows = torch.randperm(M, device="cuda")[:64]
+    want = (a[rows].to(torch.int64).cpu().numpy() @ b.to(torch.int64).cpu().numpy().T)
+    assert np.array_equal(ref_acc[rows].cpu().numpy().astype(np.int64), want), "reference rows differ from int64 matmul"
+    ref_y = pq.qlinear_s8(a, xs, b, ws, None, torch.bfloat16).clone()
+    nbad = 0
+    for i in range(reps):
+        acc = pq.int_mm(a, b)
+        y = pq.qlinear_s8(a, xs, b, ws, None, torch.bfloat16)
+        if i % 10 == 9 or i == reps - 1:
+            nbad += int((acc != ref_acc).sum().item()) + int((y.view(torch.int16) != ref_y.view(torch.int16)).sum().item())
+    bad_total += nbad
+    print(f"{M}x{N}x{K}: {reps} reps, mismatching elements: {nbad}")
+print("RACE SCREEN", "CLEAN" if bad_total == 0 else f"FAILED ({bad_total})")
