@@ -80,6 +80,15 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       void* workspace, size_t workspace_bytes, void* stream);
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+/* qlinear.forward in ONE call: y[M,N] = qlinear(x[M,K]) with dynamic per-token quantisation of x (K1), the int8 MFMA GEMM
+ * and the fused dequant epilogue, output dtype = input dtype.  Scratch (xq, xs, optional split-K slabs) is carved from
+ * `workspace` (>= pq_qlinear_dyn_workspace_bytes(M,N,K), 256-byte aligned, caller-owned, reusable across calls on one
+ * stream).  Same results, bit for bit, as pq_quant_rowwise followed by pq_qlinear_s8. */
+size_t pq_qlinear_dyn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int32_t pq_qlinear_dyn(const void* x, int32_t dtype, int64_t ld_x, const int8_t* w, int64_t ldw, const float* w_scale,
+                       const void* bias, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Self-test hook: for n (x, s) fp32 bit-pattern pairs, counts in mismatches[0] the pairs whose division-free
  * code (K1/K2 hot path) differs from clamp(rne(x / s)) and in mismatches[1] the pairs whose rebuilt quotient
  * differs from the IEEE quotient.  mismatches[2] must be zeroed by the caller.  QSPEC Q4. */

@@ -199,6 +199,33 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
     return check_launch("pq_qlinear_s8");
 }
 
+// ---- one-call dynamic qlinear: K1 (x -> xq, xs in the workspace) then pq_qlinear_s8 (with split-K slabs if planned).
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t pq_qlinear_dyn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M < 0 || N < 0 || K < 0) return 0;
+    return align256((size_t)M * (size_t)K) + align256((size_t)M * sizeof(float)) + pq_qlinear_workspace_bytes(M, N, K);
+}
+
+int32_t pq_qlinear_dyn(const void* x, int32_t dtype, int64_t ld_x, const int8_t* w, int64_t ldw, const float* w_scale,
+                       const void* bias, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_dyn: unknown dtype %d", dtype);
+    if (M < 0 || N < 0 || K < 0) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_dyn: negative size");
+    if (M == 0 || N == 0) return PQ_OK;
+    const size_t need = pq_qlinear_dyn_workspace_bytes(M, N, K);
+    if (!workspace || workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "pq_qlinear_dyn: workspace %zu < %zu bytes", workspace ? workspace_bytes : (size_t)0, need);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(PQ_ERR_BAD_ALIGN, "pq_qlinear_dyn: workspace must be 256-byte aligned");
+    uint8_t* base = static_cast<uint8_t*>(workspace);
+    int8_t* xq = reinterpret_cast<int8_t*>(base);
+    float* xs = reinterpret_cast<float*>(base + align256((size_t)M * (size_t)K));
+    uint8_t* slabs = base + align256((size_t)M * (size_t)K) + align256((size_t)M * sizeof(float));
+    const size_t slab_bytes = pq_qlinear_workspace_bytes(M, N, K);
+    int32_t st = pq_quant_rowwise(x, dtype, M, K, ld_x, xq, K, xs, stream);
+    if (st != PQ_OK) return st;
+    return pq_qlinear_s8(xq, K, xs, w, ldw, w_scale, bias, y, ldy, dtype, M, N, K, slab_bytes ? slabs : nullptr, slab_bytes, stream);
+}
+
 int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits, int64_t n, unsigned long long* mismatches, void* stream) {
     if (!x_bits || !s_bits || !mismatches || n < 0) return fail(PQ_ERR_BAD_ARG, "pq_selftest_fast_quotient: bad arguments");
     pq::launch_fast_quotient_check(x_bits, s_bits, n, mismatches, static_cast<hipStream_t>(stream));

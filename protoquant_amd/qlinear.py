@@ -29,6 +29,7 @@ def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
 
 
 _WORKSPACES: dict = {}
+_RETIRED: list = []
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
@@ -36,6 +37,8 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     key = (device.type, device.index)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _RETIRED.append(buf)      # a captured hipGraph may still hold its address: never free a workspace
         buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         _WORKSPACES[key] = buf
     return buf
@@ -62,6 +65,32 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
                                       M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes,
                                       L.stream_ptr(xq)), "qlinear_s8")
     return y
+
+
+def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) -> torch.Tensor:
+    """x[..., K] -> y[..., N]: dynamic per-token quant + int8 GEMM + fused dequant in ONE C-ABI call (pq_qlinear_dyn);
+    the scratch (xq, xs, split-K slabs) lives in the per-device workspace."""
+    L.require_gpu(x, "qlinear(x)")
+    code = L.dtype_code(x.dtype)
+    K = x.shape[-1]
+    lead = 1
+    for d in x.shape[:-1]:
+        lead *= d
+    x2 = L.row_major_2d(x.reshape(lead, K))
+    wq = L.row_major_2d(wq)
+    N = wq.shape[0]
+    if wq.shape[1] != K:
+        raise ValueError(f"shape mismatch: x has K={K}, weight has K={wq.shape[1]}")
+    if bias is not None and bias.dtype != x.dtype:
+        bias = bias.to(x.dtype)
+    y = torch.empty((lead, N), dtype=x.dtype, device=x.device)
+    wbytes = L.lib().pq_qlinear_dyn_workspace_bytes(lead, N, K)
+    wsp = _workspace(x.device, max(wbytes, 256))
+    with torch.cuda.device(x.device):
+        L.check(L.lib().pq_qlinear_dyn(x2.data_ptr(), code, L.ld(x2), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
+                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), max(N, 1),
+                                       lead, N, K, wsp.data_ptr(), wsp.numel(), L.stream_ptr(x)), "qlinear_dyn")
+    return y.reshape(*x.shape[:-1], N)
 
 
 class qlinear(nn.Module):
@@ -113,9 +142,7 @@ class qlinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[-1] != self.in_features:
             raise ValueError(f"qlinear: expected last dim {self.in_features}, got {x.shape[-1]}")
-        xq = quantize(x, axis=-1)
-        y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, x.dtype)
-        return y.reshape(*x.shape[:-1], self.out_features)
+        return qlinear_dyn(x, self.wq, self.ws, self.bias)
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"

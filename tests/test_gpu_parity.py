@@ -477,6 +477,20 @@ def test_qlinear_state_dict_roundtrip(pq):
     assert sorted(m.state_dict()) == ["bias", "wq", "ws"]
 
 
+def test_qlinear_dyn_matches_two_call_path(pq):
+    """pq_qlinear_dyn (one call, workspace scratch) == quantize() + qlinear_s8(), incl. a split-K shape and [..., K] input."""
+    torch.manual_seed(31)
+    for (lead, K, N, dt, bias) in (((7, 33), 512, 384, torch.bfloat16, True), ((512,), 4096, 1024, torch.bfloat16, False),
+                                   ((50,), 200, 130, torch.float32, True), ((300,), 256, 256, torch.float16, False)):
+        x = torch.randn(*lead, K, device="cuda").to(dt)
+        lin = torch.nn.Linear(K, N, bias=bias, device="cuda", dtype=dt)
+        m = pq.qlinear.from_linear(lin)
+        y1 = m(x)                                                       # forward() uses the one-call path
+        q = pq.quantize(x)
+        y2 = pq.qlinear_s8(q.int_data.reshape(-1, K), q.scale, m.wq, m.ws, m.bias, dt).reshape(*lead, N)
+        assert y1.shape == y2.shape and torch.equal(y1.contiguous().view(torch.uint8), y2.contiguous().view(torch.uint8))
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
