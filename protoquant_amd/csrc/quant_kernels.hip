@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256) void quant_rowwise_generic(const void* __restr
 // order like unsigned ints -> atomicMax on uint32) into `scale`; launch 2: encode with the per-column
 // scale (division-free exact quotient when every column of the wave allows it); launch 3:
 // scale[c] = scale_of(amax[c]) in place.  Loads are unrolled 4 rows deep (independent, clamped addresses).
+constexpr int kColUnroll = 8;     // independent row loads per thread per iteration (bytes in flight)
+
 template <int DT, bool VEC>
 __global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, int64_t rows, int64_t ncolv,
                                                 int64_t ldx_bytes, uint32_t* __restrict__ amax_bits, int rows_per_block) {
@@ -270,17 +272,17 @@ __global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, i
 #pragma unroll
     for (int j = 0; j < EPV; ++j) m[j] = 0.0f;
     const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
-    for (int64_t r = r0 + w; r < r1; r += 16) {
-        float f[4][EPV];
+    for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
+        float f[kColUnroll][EPV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kColUnroll; ++u) {
             const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
             const uint8_t* p = col + rr * ldx_bytes;
             if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
             else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kColUnroll; ++u)
 #pragma unroll
             for (int j = 0; j < EPV; ++j) m[j] = amax_step(m[j], f[u][j]);
     }
@@ -321,17 +323,17 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     }
     const bool fast = __builtin_amdgcn_ballot_w64(!ok) == 0;      // wave-uniform
     const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
-    for (int64_t r = r0 + w; r < r1; r += 16) {
-        float f[4][EPV];
+    for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
+        float f[kColUnroll][EPV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kColUnroll; ++u) {
             const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
             const uint8_t* p = col + rr * ldx_bytes;
             if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
             else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kColUnroll; ++u) {
             const int64_t rr = r + 4 * u;
             int c[EPV];
             if (fast) {
@@ -448,7 +450,12 @@ void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) && aligned(q, EPV);
     const int64_t ncolv = vec_ok ? cols / EPV : cols;
-    const int rpb = 64;
+    // rows per block: aim at ~320 blocks (measured sweet spot 256-450: fewer blocks starve HBM, more pay per-block
+    // LDS reductions and atomics), in multiples of one unrolled batch
+    const int64_t strips = (ncolv + 63) / 64;
+    int64_t rpb64 = (rows * strips + 319) / 320;
+    rpb64 = (rpb64 + 4 * kColUnroll - 1) / (4 * kColUnroll) * (4 * kColUnroll);
+    const int rpb = (int)(rpb64 < 4 * kColUnroll ? 4 * kColUnroll : (rpb64 > 4096 ? 4096 : rpb64));
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((ncolv + 63) / 64)), block(256);
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const int64_t ldb = ldx * Elem<DT>::kBytes;
