@@ -491,6 +491,30 @@ def test_qlinear_dyn_matches_two_call_path(pq):
         assert y1.shape == y2.shape and torch.equal(y1.contiguous().view(torch.uint8), y2.contiguous().view(torch.uint8))
 
 
+def test_qlinear_is_graph_capturable(pq):
+    """The C-ABI neither allocates nor synchronises: a qlinear forward (incl. a split-K shape) can be captured in a
+    hipGraph and replayed on new inputs with the same bits as the eager call."""
+    torch.manual_seed(41)
+    for (M, K, N) in ((256, 512, 384), (512, 4096, 1024)):
+        m = pq.qlinear.from_linear(torch.nn.Linear(K, N, bias=True, device="cuda", dtype=torch.bfloat16))
+        x_static = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        m(x_static)                                        # warm up: workspace allocated outside the capture
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x_static)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y_static = m(x_static)
+        for _ in range(3):
+            x_new = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+            x_static.copy_(x_new)
+            g.replay()
+            want = m(x_new)
+            torch.cuda.synchronize()
+            assert torch.equal(y_static.view(torch.int16), want.view(torch.int16))
+
+
 def test_errors_are_loud(pq):
     from protoquant_amd import _lib
     with pytest.raises(_lib.PQError):
