@@ -74,6 +74,57 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
     } else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
 }
 
+// Tail split: a grid of T > 256 tiles runs ceil(T/256) rounds of one 256x256 tile per CU, and the last round is as long as
+// the others however few tiles it holds.  When that round is poorly filled, the trailing tile columns (or rows) go to a
+// second launch of 128(m) x 256(n) tiles instead — twice the blocks, each ~0.65 of a full tile's time (measured) — so
+// e.g. 344 tiles cost 1 + 0.65 rounds instead of 2.  Both launches are plain sub-problems (pointer offsets), results are
+// unchanged bit for bit.  Returns the split axis (0 none, 1 along N, 2 along M) and the extent of the leading part.
+constexpr double kHalfTileCost = 0.65, kSecondLaunchCost = 0.06;
+
+int tail_split_plan(int64_t M, int64_t N, int64_t* lead) {
+    if (getenv("PQ_NO_TAILSPLIT")) return 0;
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
+    if (tiles <= 256) return 0;
+    auto rounds = [](int64_t blocks) { return (double)((blocks + 255) / 256); };
+    double best = rounds(tiles) - 0.12;   // a split must save at least ~1/8 of a round to be worth a second launch
+    int axis = 0;
+    const int64_t hm = (M + 127) / 128;
+    for (int64_t c = 1; c < tn; ++c) {    // trailing c tile columns, all rows, as 128-row tiles
+        if (hm * c > 512) break;
+        const double cost = rounds(tm * (tn - c)) + rounds(hm * c) * kHalfTileCost + kSecondLaunchCost;
+        if (cost < best) { best = cost; axis = 1; *lead = (tn - c) * 256; }
+    }
+    for (int64_t r = 1; r < tm; ++r) {    // trailing r tile rows, all columns
+        const int64_t tail_h = (M - (tm - r) * 256 + 127) / 128;
+        if (tail_h * tn > 512) break;
+        const double cost = rounds((tm - r) * tn) + rounds(tail_h * tn) * kHalfTileCost + kSecondLaunchCost;
+        if (cost < best) { best = cost; axis = 2; *lead = (tm - r) * 256; }
+    }
+    return axis;
+}
+
+template <int OUT>
+void run_gemm_auto(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
+                   int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    int64_t lead = 0;
+    const int axis = (v == V_SP256_16 && forced_variant() == V_AUTO) ? tail_split_plan(M, N, &lead) : 0;
+    if (axis == 0) return run_gemm<OUT>(v, a, lda, b, ldb, epi, M, N, K, st);
+    using elem_t = typename pq::OutElem<OUT>::type;
+    pq::EpiArgs tail = epi;
+    if (axis == 1) {
+        tail.b_scale = epi.b_scale ? epi.b_scale + lead : nullptr;
+        tail.bias = epi.bias ? static_cast<const elem_t*>(epi.bias) + lead : nullptr;
+        tail.y = static_cast<elem_t*>(epi.y) + lead;
+        run_gemm<OUT>(V_SP256_16, a, lda, b, ldb, epi, M, lead, K, st);
+        run_gemm<OUT>(V_SP128_16, a, lda, b + lead * ldb, ldb, tail, M, N - lead, K, st);
+    } else {
+        tail.a_scale = epi.a_scale ? epi.a_scale + lead : nullptr;
+        tail.y = static_cast<elem_t*>(epi.y) + lead * epi.ldy;
+        run_gemm<OUT>(V_SP256_16, a, lda, b, ldb, epi, lead, N, K, st);
+        run_gemm<OUT>(V_SP128_16, a + lead * lda, lda, b, ldb, tail, M - lead, N, K, st);
+    }
+}
+
 bool bad_mat(const void* p, int64_t rows, int64_t cols, int64_t ld) {
     return rows < 0 || cols < 0 || ld < cols || (rows > 0 && cols > 0 && p == nullptr);
 }
@@ -137,7 +188,7 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
         return fail(PQ_ERR_BAD_ARG, "pq_gemm_s8s8s32: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldc);
     if (M == 0 || N == 0) return PQ_OK;
     pq::EpiArgs epi{nullptr, nullptr, nullptr, c, ldc};
-    run_gemm<pq::OUT_I32>(pick_variant(a, lda, b, ldb, M, N, K), a, lda, b, ldb, epi, M, N, K, static_cast<hipStream_t>(stream));
+    run_gemm_auto<pq::OUT_I32>(pick_variant(a, lda, b, ldb, M, N, K), a, lda, b, ldb, epi, M, N, K, static_cast<hipStream_t>(stream));
     return check_launch("pq_gemm_s8s8s32");
 }
 
@@ -192,9 +243,9 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
         return check_launch("pq_qlinear_s8 (split-K)");
     }
     switch (out_dtype) {
-        case PQ_BF16: run_gemm<PQ_BF16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
-        case PQ_FP16: run_gemm<PQ_FP16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
-        default: run_gemm<PQ_F32>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+        case PQ_BF16: run_gemm_auto<PQ_BF16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+        case PQ_FP16: run_gemm_auto<PQ_FP16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
+        default: run_gemm_auto<PQ_F32>(v, a, lda, b, ldb, epi, M, N, K, st); break;
     }
     return check_launch("pq_qlinear_s8");
 }
@@ -239,7 +290,11 @@ void pq_dev_set_stamp_buffer(unsigned long long* p) { pq::set_stamp_buffer(p); }
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     // alignment of the pointers is unknown here: assume 16-byte aligned bases
     switch (pick_variant(reinterpret_cast<const int8_t*>(16), lda, reinterpret_cast<const int8_t*>(16), ldb, M, N, K)) {
-        case V_SP256_16: return "sp256_16x16x64";
+        case V_SP256_16: {
+            int64_t lead = 0;
+            const int axis = forced_variant() == V_AUTO ? tail_split_plan(M, N, &lead) : 0;
+            return axis == 1 ? "sp256_16x16x64 + sp128 tail (N)" : axis == 2 ? "sp256_16x16x64 + sp128 tail (M)" : "sp256_16x16x64";
+        }
         case V_SP256_32: return "sp256_32x32x32";
         case V_SP128_16: return "sp128x256_16x16x64";
         default: return "generic64";

@@ -221,6 +221,28 @@ def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     same(pq.qlinear_s8(*args), want, "single-pass y")
 
 
+@pytest.mark.parametrize("M,N,K,code,bias", [(2048, 11008, 128, 0, True), (4096, 4352, 128, 1, False), (11008, 2048, 128, 0, True),
+                                              (2050, 10990, 256, 2, True)])
+def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
+    """Grids a little over a whole number of rounds: the trailing tile columns/rows run as a second launch of 128-row
+    tiles.  Result == the oracle, == the single launch (PQ_NO_TAILSPLIT), and the int32 twin stays exact."""
+    from protoquant_amd import _lib
+    assert b"tail" in _lib.lib().pq_gemm_variant_name(M, N, K, K, K), "shape should be planned with a tail launch"
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
+    acc = (a.astype(np.int32) @ b.astype(np.int32).T)
+    want = Q.epilogue(acc, xs, ws, bv, code)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    args = (ta, torch.from_numpy(xs).cuda(), tb, torch.from_numpy(ws).cuda(), to_gpu(bv, code) if bias else None, TD[code])
+    same(pq.qlinear_s8(*args), want, "tail-split y")
+    same(pq.int_mm(ta, tb), acc, "tail-split acc")
+    monkeypatch.setenv("PQ_NO_TAILSPLIT", "1")
+    assert b"tail" not in _lib.lib().pq_gemm_variant_name(M, N, K, K, K)
+    same(pq.qlinear_s8(*args), want, "single-launch y")
+
+
 def test_splitk_workspace_too_small_is_an_error(pq):
     from protoquant_amd import _lib
     L = _lib.lib()
