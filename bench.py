@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
@@ -89,8 +90,9 @@ def cpu_baseline(M, N, K):
 
 
 def run_mlp(args):
-    """BASELINE configs[2]: gate/up (horizontally fused, N = 2 x 11008) and down as qlinear at M = 2048; the
-    silu(g)*u in between is stock torch-ROCm elementwise.  One step = the whole block; 554.05 GOP of int8 GEMM."""
+    """BASELINE configs[2]: gate/up (horizontally fused, N = 2 x 11008) and down as qlinear at M = 2048; silu(g)*u is
+    fused into the quantisation of down's input (pq_silu_mul_quant_rowwise; --unfused-silu restores the stock torch-ROCm
+    elementwise + K1 pair).  One step = the whole block; 554.05 GOP of int8 GEMM."""
     import protoquant_amd as pq
     M, H, I = 2048, 4096, 11008
     dev = torch.device("cuda", 0)
@@ -100,9 +102,15 @@ def run_mlp(args):
     gate_up = pq.FusedQLinear([mk(I, H), mk(I, H)])
     down = mk(H, I)
 
-    def block():
-        gt, up = gate_up(x)
-        return down(torch.nn.functional.silu(gt) * up)
+    if args.unfused_silu:
+        def block():
+            gt, up = gate_up(x)
+            return down(torch.nn.functional.silu(gt) * up)
+    else:
+        mlp = pq.GatedMLP(gate_up, down)       # silu*mul fused into the quantisation of down's input (one pass, no bf16 h)
+
+        def block():
+            return mlp(x)
 
     for _ in range(args.warmup):
         block()
@@ -134,10 +142,11 @@ def run_mlp(args):
                       "unit": "TOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": "Llama MLP block 4096->11008->4096, seq 2048, gate+up fused (BASELINE configs[2])",
+                                 "silu_mul": "torch elementwise + K1" if args.unfused_silu else "fused into K1 (pq_silu_mul_quant_rowwise)",
                                  "launch": "hipgraph" if graph is not None else "eager"},
                       "roofline": {"bound": "mfma", "achieved": round(ops * args.steps / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops * args.steps / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "whole block incl. two quant passes and the torch silu*mul, not a single kernel"},
+                                   "note": "whole block incl. both activation quantisations (the second fused with silu*mul), not a single kernel"},
                       "cpu_baseline": None}), flush=True)
 
 
@@ -165,7 +174,10 @@ def run_llama8b(args):
             a = qkv(x)[:, :H].contiguous()
             x = o(a)
             g_u = gu(x)
-            x = down(torch.nn.functional.silu(g_u[:, :I]) * g_u[:, I:])
+            if args.unfused_silu:
+                x = down(torch.nn.functional.silu(g_u[:, :I]) * g_u[:, I:])
+            else:
+                x = down(pq.silu_mul_quantize(g_u[:, :I], g_u[:, I:]))
         return head(x)
 
     for _ in range(2):
@@ -184,7 +196,7 @@ def run_llama8b(args):
                                  "launch": "eager", "int8_ops_per_step": ops},
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "whole pass incl. quant passes and torch elementwise glue"},
+                                   "note": "whole pass incl. every activation quantisation (silu*mul fused into down's) and the qkv slice copy"},
                       "cpu_baseline": None}), flush=True)
 
 

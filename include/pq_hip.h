@@ -57,6 +57,15 @@ int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t col
 int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x,
                          int8_t* q, int64_t ld_q, float* scale, void* stream);
 
+/* K1 fused into its producer: quantize(F.silu(g) * u) per token in one pass — the activation of the
+ * `down` projection of a gated MLP (BASELINE config 3) — so the bf16 product never goes to HBM.  g, u: [rows, cols] of
+ * `dtype` with their own leading dimensions (the two column halves of a fused gate+up output qualify: ld = 2*cols).
+ * h_out (nullable, ld_h): also store h = silu(g)*u in `dtype`.  Numerics: QSPEC S1-S6 (specified exponential, IEEE
+ * division, storage rounding after silu and after the product), then Q1-Q6 on the rows of h. */
+int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype,
+                                  int64_t rows, int64_t cols, int8_t* q, int64_t ld_q, float* scale,
+                                  void* h_out, int64_t ld_h, void* stream);
+
 /* dequantize(): out[r,c] = cast_rne(f32(q[r,c]) * scale[axis==0 ? c : r]).  `axis` is the axis the
  * scale was reduced over (1: one scale per row, 0: one scale per column).   QSPEC D1. */
 int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis,

@@ -86,3 +86,22 @@ def qlinear_s8(a, a_scale, b, b_scale, bias, out_dtype: int):
     lib().oq_qlinear_s8(_p(a), i64(K), _p(a_scale), _p(b), i64(K), _p(b_scale), _p(bias), _p(y), i64(N),
                         out_dtype, i64(M), i64(N), i64(K))
     return y
+
+
+def exp_spec(t: np.ndarray) -> np.ndarray:
+    L = lib()
+    L.oq_exp_spec.restype = ctypes.c_float
+    L.oq_exp_spec.argtypes = [ctypes.c_float]
+    t = np.asarray(t, np.float32)
+    return np.array([L.oq_exp_spec(float(v)) for v in t.ravel()], np.float32).reshape(t.shape)
+
+
+def silu_mul_quant_rowwise(g: np.ndarray, u: np.ndarray, dtype: int, want_h: bool = True):
+    """QSPEC S1-S6.  g, u: [rows, cols] stored dtype.  Returns (q, scale, h or None)."""
+    g = np.ascontiguousarray(g); u = np.ascontiguousarray(u)
+    r, c = g.shape
+    q = np.zeros((r, c), np.int8)
+    s = np.zeros(r, np.float32)
+    h = np.zeros((r, c), _store(dtype)) if want_h else None
+    lib().oq_silu_mul_quant_rowwise(_p(g), i64(c), _p(u), i64(c), dtype, i64(r), i64(c), _p(q), i64(c), _p(s), _p(h), i64(c))
+    return q, s, h

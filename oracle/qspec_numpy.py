@@ -101,3 +101,64 @@ def qlinear(x, dtype, wq, ws, bias=None):
     acc = gemm_s8s8s32(xq, wq)
     y = epilogue(acc, xs, ws, bias, dtype)
     return y, xq, xs, acc
+
+
+# ---------------------------------------------------------------- QSPEC S1-S6: silu(g)*u -> per-token quantisation
+def _bits(u: int) -> np.float32:
+    return np.array([u], np.uint32).view(np.float32)[0]
+
+
+def fma32(a, b, c) -> np.ndarray:
+    """Correctly rounded binary32 fma(a, b, c) without a hardware fma: the product is exact in binary64, the sum is
+    rounded to 53 bits with its error recovered by TwoSum, and the one case where rounding 53 -> 24 bits could go wrong
+    (the 53-bit sum sits exactly on a binary32 tie while the true sum does not) is decided by the sign of that error."""
+    a = np.asarray(a, np.float32).astype(np.float64); b = np.asarray(b, np.float32).astype(np.float64)
+    c = np.asarray(c, np.float32).astype(np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        p = a * b
+        s = p + c
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)
+        lo = s.astype(np.float32)
+        lo64 = lo.astype(np.float64)
+        toward = np.where(s > lo64, np.float32(np.inf), np.float32(-np.inf))
+        nb = np.nextafter(lo, toward)
+        tie = np.isfinite(s) & (s != lo64) & (np.abs(s - lo64) == np.abs(s - nb.astype(np.float64))) & (err != 0)
+        pick_nb = tie & (np.sign(err) == np.sign(nb.astype(np.float64) - lo64))
+    return np.where(pick_nb, nb, lo).astype(np.float32)
+
+
+def exp_spec(t) -> np.ndarray:
+    """QSPEC S1-S4 (oracle/qspec_oracle.c::oq_exp_spec)."""
+    t = np.asarray(t, np.float32)
+    with np.errstate(invalid="ignore", over="ignore", under="ignore"):
+        tc = np.where(t < np.float32(-30), np.float32(-30), t)
+        tc = np.where(tc > np.float32(100), np.float32(100), tc).astype(np.float32)
+        n = np.rint(tc * _bits(0x3FB8AA3B)).astype(np.float32)
+        r = fma32(n, -_bits(0x3F317200), tc)
+        r = fma32(n, -_bits(0x35BFBE8E), r)
+        p = np.full(t.shape, _bits(0x39500D01), np.float32)
+        for cbits in (0x3AB60B61, 0x3C088889, 0x3D2AAAAB, 0x3E2AAAAB, 0x3F000000, 0x3F800000, 0x3F800000):
+            p = fma32(p, r, np.full(t.shape, _bits(cbits), np.float32))
+        ni = np.where(np.isnan(n), 0, n).astype(np.int32)
+        n1 = ni >> 1
+        n2 = ni - n1
+        s1 = ((n1 + 127).astype(np.uint32) << np.uint32(23)).view(np.float32)
+        s2 = ((n2 + 127).astype(np.uint32) << np.uint32(23)).view(np.float32)
+        return ((p * s1).astype(np.float32) * s2).astype(np.float32)
+
+
+def silu_mul(g: np.ndarray, u: np.ndarray, dtype) -> np.ndarray:
+    """QSPEC S5: h = cast(f32(cast(g / (1 + exp_spec(-g)))) * f32(u)), stored dtype out."""
+    gf, uf = to_f32(g, dtype), to_f32(u, dtype)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        d = (np.float32(1) + exp_spec(-gf)).astype(np.float32)
+        sg = to_f32(from_f32((gf / d).astype(np.float32), dtype), dtype)
+        return from_f32((sg * uf).astype(np.float32), dtype)
+
+
+def silu_mul_quantize(g: np.ndarray, u: np.ndarray, dtype):
+    """QSPEC S6: per-token quantisation of silu_mul(g, u).  Returns (q int8, scale f32, h stored dtype)."""
+    h = silu_mul(g, u, dtype)
+    q, s = quantize(h, dtype, 1)
+    return q, s, h

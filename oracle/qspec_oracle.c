@@ -146,3 +146,64 @@ void oq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
             store_f32(y, out_dtype, m * ldy + n, t);
         }
 }
+
+/* ---- QSPEC S1-S6: silu(g)*u -> per-token quantisation, the producer-fused form of
+ *      quantize(F.silu(g) * u)   (BASELINE config 3 names the silu*mul between up and down).
+ * The exponential is SPECIFIED (not "libm's exp"), so every implementation produces the same bits:
+ * Cody-Waite reduction + degree-7 Taylor polynomial, all in binary32 with correctly rounded fmaf. */
+static inline float f32_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float oq_exp_spec(float t) {
+    /* S1: clamp (a NaN fails both compares and passes through) */
+    float tc = t < -30.0f ? -30.0f : t;
+    tc = tc > 100.0f ? 100.0f : tc;
+    /* S2: n = rne(tc * log2(e));  r = tc - n*ln2 in two fma steps (ln2 = hi + lo, hi has 9 trailing zero bits) */
+    const float n = rintf(tc * f32_bits(0x3FB8AA3Bu));
+    float r = fmaf(n, -f32_bits(0x3F317200u), tc);
+    r = fmaf(n, -f32_bits(0x35BFBE8Eu), r);
+    /* S3: e^r = 1 + r(1 + r(1/2 + r(1/6 + r(1/24 + r(1/120 + r(1/720 + r/5040)))))), Horner with fmaf */
+    float p = f32_bits(0x39500D01u);
+    p = fmaf(p, r, f32_bits(0x3AB60B61u));
+    p = fmaf(p, r, f32_bits(0x3C088889u));
+    p = fmaf(p, r, f32_bits(0x3D2AAAABu));
+    p = fmaf(p, r, f32_bits(0x3E2AAAABu));
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    /* S4: scale by 2^n in two exact steps (n in [-43, 144]; the second may overflow to +inf, as exp does) */
+    const int32_t ni = (n == n) ? (int32_t)n : 0;
+    const int32_t n1 = ni >> 1, n2 = ni - n1;          /* arithmetic shift: floor(n/2) */
+    return (p * f32_bits((uint32_t)(n1 + 127) << 23)) * f32_bits((uint32_t)(n2 + 127) << 23);
+}
+
+/* S5: h = cast(f32(cast(g / (1 + exp_spec(-g)))) * f32(u)) — the storage-dtype rounding after silu and after the
+ * product mirrors the two eager ops F.silu(g) and (...) * u. */
+static inline float silu_mul_spec(float g, float u, int dtype) {
+    const float d = 1.0f + oq_exp_spec(-g);
+    float sg = g / d;
+    if (dtype == OQ_BF16) sg = bf16_to_f32(f32_to_bf16(sg));
+    else if (dtype == OQ_FP16) sg = fp16_to_f32(f32_to_fp16(sg));
+    return sg * u;    /* the caller rounds the product to the storage dtype */
+}
+
+/* S6: Q1-Q6 on the rows of h.  g[rows, cols] (ld ldg), u[rows, cols] (ld ldu), same dtype; h_out nullable. */
+void oq_silu_mul_quant_rowwise(const void* g, int64_t ldg, const void* u, int64_t ldu, int dtype, int64_t rows,
+                               int64_t cols, int8_t* q, int64_t ldq, float* scale, void* h_out, int64_t ldh) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        float amax = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            const float s = scale_of(amax);
+            if (pass == 1) scale[r] = s;
+            for (int64_t c = 0; c < cols; ++c) {
+                float h = silu_mul_spec(load_f32(g, dtype, r * ldg + c), load_f32(u, dtype, r * ldu + c), dtype);
+                if (dtype == OQ_BF16) h = bf16_to_f32(f32_to_bf16(h));
+                else if (dtype == OQ_FP16) h = fp16_to_f32(f32_to_fp16(h));
+                if (pass == 0) {
+                    amax = amax_step(amax, h);
+                    if (h_out) store_f32(h_out, dtype, r * ldh + c, h);
+                } else q[r * ldq + c] = code_of(h, s);
+            }
+        }
+    }
+}

@@ -10,6 +10,7 @@
 namespace pq {
 template <int DT> void quant_rowwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template <int DT> void quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template <int DT> void silu_mul_quant_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE, int TM> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
@@ -164,6 +165,22 @@ int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t col
         default: pq::quant_colwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
     }
     return check_launch("pq_quant_colwise");
+}
+
+int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows,
+                                  int64_t cols, int8_t* q, int64_t ld_q, float* scale, void* h_out, int64_t ld_h, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_quant_rowwise: unknown dtype %d", dtype);
+    if (bad_mat(g, rows, cols, ld_g) || bad_mat(u, rows, cols, ld_u) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale) ||
+        (h_out && ld_h < cols))
+        return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_quant_rowwise: bad matrix (rows=%lld cols=%lld ld_g=%lld ld_u=%lld ld_q=%lld ld_h=%lld)", (long long)rows, (long long)cols, (long long)ld_g, (long long)ld_u, (long long)ld_q, (long long)ld_h);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::silu_mul_quant_dispatch<PQ_BF16>(g, ld_g, u, ld_u, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+        case PQ_FP16: pq::silu_mul_quant_dispatch<PQ_FP16>(g, ld_g, u, ld_u, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+        default: pq::silu_mul_quant_dispatch<PQ_F32>(g, ld_g, u, ld_u, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+    }
+    return check_launch("pq_silu_mul_quant_rowwise");
 }
 
 int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis, int64_t rows, int64_t cols,

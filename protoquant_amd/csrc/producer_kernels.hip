@@ -1,0 +1,373 @@
+// producer_kernels.hip — K1 fused into the elementwise op that produces the activation:
+//   silu(g) * u  ->  per-token int8 codes + row scales, without the bf16 activation ever going to HBM.
+// Same skeleton as K1 (quant_kernels.hip): TPR threads own a row, the row of h lives in registers between the amax
+// reduction and the encode; here it is COMPUTED from one 16-byte vector of g and one of u per slot instead of loaded.
+// Arithmetic follows QSPEC S1-S6: a specified exponential (Cody-Waite + degree-7 Horner with fma),
+// IEEE division, storage-dtype rounding after silu and after the product — bit-identical to oracle/qspec_oracle.c.
+// Algorithmic traffic: read 2 x elem bytes, write 1 B/elem + 4 B/row (+ elem bytes when h is also requested).
+#include <type_traits>
+
+#include "quant_device.h"
+
+namespace pq {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two elements at a time: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate of their scalar forms,
+// and one v_cvt_pk_bf16_f32 rounds both.  This kernel is VALU-bound before it is HBM-bound (about 50 scalar VALU ops
+// per element against 5 bytes), so the pairing is what moves it.
+__device__ __forceinline__ v2f splat(float v) { return v2f{v, v}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int DT> struct Pair;            // one 32-bit word of storage <-> two floats
+template <> struct Pair<PQ_BF16> {
+    typedef __bf16 st2 __attribute__((ext_vector_type(2)));
+    __device__ static __forceinline__ v2f unpack(uint32_t w) { return v2f{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)}; }
+    __device__ static __forceinline__ uint32_t pack(v2f f) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, st2)); }
+};
+template <> struct Pair<PQ_FP16> {
+    typedef _Float16 st2 __attribute__((ext_vector_type(2)));
+    __device__ static __forceinline__ v2f unpack(uint32_t w) { return __builtin_convertvector(__builtin_bit_cast(st2, w), v2f); }
+    __device__ static __forceinline__ uint32_t pack(v2f f) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, st2)); }
+};
+
+// QSPEC S1-S5 on NP pairs at once, written stage by stage so that NP independent instructions follow each other: one
+// wave's dependent v_pk_fma chain leaves the VALU idle most of the time (measured: 2x off the issue rate), NP chains do
+// not.  Notes on the forms used:
+//  - the clamp is v_med3_f32 (a NaN comes out finite): the only consumer divides g by 1 + exp(-g), so a NaN g still
+//    yields NaN, exactly as the specification's pass-through does;
+//  - ldexp(p, n) equals the specification's two exact power-of-two multiplications for every n in [-43, 144];
+//  - FASTDIV: the IEEE quotient g / d without v_div_scale / v_div_fmas / v_div_fixup, which serialise on VCC and run at
+//    ~6 results/clk/CU against ~100 for an fma (tools/ubench/valu_rate).  It is the arithmetic core of the hardware's own
+//    correctly rounded sequence — rcp, one Newton step, the quotient and two residual corrections — without the operand
+//    scaling, which is only needed when an intermediate can overflow or lose bits to underflow.  For 0 < |g| <= 86 none
+//    can: d lies in [1, 2^125), the residuals g - d*q are exact (for |g| < 2^-25, d is exactly 2 and every step is an exact
+//    scaling).  Waves holding a zero (whose sign the residual steps would lose), |g| > 86, Inf or NaN take the `/` path
+//    (silu_fast_div_ok, decided once per wave).
+// Returns the products BEFORE their storage rounding.
+template <int DT, bool FASTDIV, int NP>
+__device__ __forceinline__ void silu_mul_stage(const v2f (&g)[NP], const v2f (&u)[NP], v2f (&h)[NP]) {
+    v2f tc[NP], n[NP], r[NP], p[NP], d[NP], sg[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) tc[k] = v2f{__builtin_amdgcn_fmed3f(-g[k].x, -30.0f, 100.0f), __builtin_amdgcn_fmed3f(-g[k].y, -30.0f, 100.0f)};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) n[k] = tc[k] * splat(__builtin_bit_cast(float, 0x3FB8AA3Bu));
+#pragma unroll
+    for (int k = 0; k < NP; ++k) n[k] = v2f{__builtin_rintf(n[k].x), __builtin_rintf(n[k].y)};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) r[k] = pk_fma(n[k], splat(-__builtin_bit_cast(float, 0x3F317200u)), tc[k]);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) r[k] = pk_fma(n[k], splat(-__builtin_bit_cast(float, 0x35BFBE8Eu)), r[k]);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) p[k] = pk_fma(splat(__builtin_bit_cast(float, 0x39500D01u)), r[k], splat(__builtin_bit_cast(float, 0x3AB60B61u)));
+    constexpr uint32_t kC[6] = {0x3C088889u, 0x3D2AAAABu, 0x3E2AAAABu, 0x3F000000u, 0x3F800000u, 0x3F800000u};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) p[k] = pk_fma(p[k], r[k], splat(__builtin_bit_cast(float, kC[c])));
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) d[k] = splat(1.0f) + v2f{__builtin_ldexpf(p[k].x, (int)n[k].x), __builtin_ldexpf(p[k].y, (int)n[k].y)};
+    if constexpr (FASTDIV) {
+        v2f y0[NP], y[NP], q[NP], e[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) y0[k] = v2f{__builtin_amdgcn_rcpf(d[k].x), __builtin_amdgcn_rcpf(d[k].y)};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) e[k] = pk_fma(-d[k], y0[k], splat(1.0f));
+#pragma unroll
+        for (int k = 0; k < NP; ++k) y[k] = pk_fma(e[k], y0[k], y0[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) q[k] = g[k] * y[k];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) e[k] = pk_fma(-d[k], q[k], g[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) q[k] = pk_fma(e[k], y[k], q[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) e[k] = pk_fma(-d[k], q[k], g[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sg[k] = pk_fma(e[k], y[k], q[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sg[k] = v2f{g[k].x / d[k].x, g[k].y / d[k].y};
+    }
+    if constexpr (DT != PQ_F32) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sg[k] = Pair<DT>::unpack(Pair<DT>::pack(sg[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) h[k] = sg[k] * u[k];
+}
+template <int DT>
+__device__ __forceinline__ float silu_mul_spec(float g, float u) {
+    const v2f ga[1] = {v2f{g, g}}, ua[1] = {v2f{u, u}};
+    v2f h[1];
+    silu_mul_stage<DT, false, 1>(ga, ua, h);
+    return h[0].x;
+}
+
+// min / max of |g| over one 16-byte vector, on raw bit patterns (the same ordering trick as vec_amax_bits)
+template <int DT>
+__device__ __forceinline__ void vec_absminmax_bits(const v4u& v, uint32_t& mn, uint32_t& mx) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (DT == PQ_F32) {
+            const uint32_t a = v[i] & 0x7FFFFFFFu;
+            mn = a < mn ? a : mn;
+            mx = a > mx ? a : mx;
+        } else {
+            const uint32_t a = v[i] & 0x7FFF7FFFu, lo = a & 0xFFFFu, hi = a >> 16;
+            mn = min(mn, min(lo, hi));
+            mx = max(mx, max(lo, hi));
+        }
+    }
+}
+template <int DT> __device__ __forceinline__ bool silu_fast_div_ok(uint32_t mn, uint32_t mx) {
+    constexpr uint32_t k86 = DT == PQ_F32 ? 0x42AC0000u : (DT == PQ_BF16 ? 0x42ACu : 0x5560u);   // 86.0
+    return mn != 0u && mx <= k86;
+}
+
+// one 16-byte vector of g and of u -> one 16-byte vector of h in the storage dtype
+template <int DT, bool FASTDIV>
+__device__ __forceinline__ v4u silu_mul_vec(const v4u& gv, const v4u& uv) {
+    constexpr int NP = DT == PQ_F32 ? 2 : 4;
+    v2f g[NP], u[NP], h[NP];
+    v4u out;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if constexpr (DT == PQ_F32) {
+            const uint32_t g0 = gv[2 * j], g1 = gv[2 * j + 1], u0 = uv[2 * j], u1 = uv[2 * j + 1];   // copies first (hipcc quirk)
+            g[j] = v2f{__builtin_bit_cast(float, g0), __builtin_bit_cast(float, g1)};
+            u[j] = v2f{__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1)};
+        } else {
+            const uint32_t gw = gv[j], uw = uv[j];
+            g[j] = Pair<DT>::unpack(gw);
+            u[j] = Pair<DT>::unpack(uw);
+        }
+    }
+    silu_mul_stage<DT, FASTDIV, NP>(g, u, h);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if constexpr (DT == PQ_F32) {
+            const float hx = h[j].x, hy = h[j].y;   // copies first: bit_cast of a vector-element lvalue reads element 0
+            out[2 * j] = __builtin_bit_cast(uint32_t, hx);
+            out[2 * j + 1] = __builtin_bit_cast(uint32_t, hy);
+        } else {
+            out[j] = Pair<DT>::pack(h[j]);
+        }
+    }
+    return out;
+}
+
+// division-free exact encode (quant_device.h) of one 16-byte vector of h, two elements per instruction
+template <int DT>
+__device__ __forceinline__ void fast_encode_vec(const v4u& hv, float s, float r, uint32_t (&pk)[(16 / Elem<DT>::kBytes) / 4]) {
+    const v2f vs = splat(s), vr = splat(r);
+    uint32_t mb[16 / Elem<DT>::kBytes];
+#pragma unroll
+    for (int j = 0; j < (16 / Elem<DT>::kBytes) / 2; ++j) {
+        v2f x;
+        if constexpr (DT == PQ_F32) {
+            const uint32_t a = hv[2 * j], b = hv[2 * j + 1];
+            x = v2f{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+        } else {
+            const uint32_t w = hv[j];
+            x = Pair<DT>::unpack(w);
+        }
+        v2f q = x * vr;
+        v2f e = pk_fma(-q, vs, x);
+        q = pk_fma(e, vr, q);
+        e = pk_fma(-q, vs, x);
+        q = pk_fma(e, vr, q);
+        const v2f m = q + splat(kMagic);
+        const float mx = m.x, my = m.y;       // copies first (same hipcc quirk)
+        mb[2 * j] = __builtin_bit_cast(uint32_t, mx);
+        mb[2 * j + 1] = __builtin_bit_cast(uint32_t, my);
+    }
+#pragma unroll
+    for (int k = 0; k < (16 / Elem<DT>::kBytes) / 4; ++k)
+        pk[k] = __builtin_amdgcn_perm(mb[4 * k + 1], mb[4 * k], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * k + 3], mb[4 * k + 2], 0x04000c0cu);
+}
+
+template <int DT, int VPT, int TPR, bool WRITE_H>
+__global__ __launch_bounds__(256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
+                                                          const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
+                                                          int nvec, int8_t* __restrict__ q, int64_t ldq,
+                                                          float* __restrict__ scale, uint8_t* __restrict__ h_out,
+                                                          int64_t ldh_bytes) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    constexpr int RPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const bool active = row < rows;
+    row = active ? row : rows - 1;
+    const uint8_t* gr = g + row * ldg_bytes;
+    const uint8_t* ur = u + row * ldu_bytes;
+
+    // every load is issued before the first use (clamped addresses: a duplicate of the tail vector changes no max)
+    v4u gv[VPT], uv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = i * TPR + t;
+        const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
+        gv[i] = *reinterpret_cast<const v4u*>(gr + off);
+        uv[i] = *reinterpret_cast<const v4u*>(ur + off);
+    }
+    v4u hv[VPT];
+    uint32_t ab = 0;
+    uint32_t gmn = 0xFFFFFFFFu, gmx = 0u;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) vec_absminmax_bits<DT>(gv[i], gmn, gmx);
+    const bool fast_div = __builtin_amdgcn_ballot_w64(!silu_fast_div_ok<DT>(gmn, gmx)) == 0ull;   // wave-uniform
+    auto produce = [&](auto fast) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            // slots past the row's end (whole waves of them when the width is not VPT * TPR vectors) skip the arithmetic
+            hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
+            ab = vec_amax_bits<DT>(hv[i], ab);
+            if constexpr (WRITE_H) {
+                if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+            }
+        }
+    };
+    if (fast_div) produce(std::true_type{});
+    else produce(std::false_type{});
+    ab = wave_max_u32(ab);
+    __shared__ uint32_t part[256 / kWave];
+    if constexpr (TPR > kWave) {
+        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
+    }
+    const bool has_nan = amax_bits_has_nan<DT>(ab);
+    float amax = amax_bits_to_f32<DT>(ab);
+    if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare on the registers
+        amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            float f[EPV];
+            Unpack<DT, EPV>::run(hv[i], f);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
+        }
+        amax = wave_max(amax);
+        if constexpr (TPR > kWave) {
+            __syncthreads();
+            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
+        }
+    }
+    const float s = scale_of(amax);
+    if (!active) return;
+    if (t == 0) scale[row] = s;
+    int8_t* qr = q + row * ldq;
+    auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
+        if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
+        else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
+    };
+    if (!has_nan && scale_fast_ok(s)) {
+        const float r = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            uint32_t pk[EPV / 4];
+            fast_encode_vec<DT>(hv[i], s, r, pk);
+            if (idx < nvec) store_vec(idx, pk);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            float f[EPV];
+            Unpack<DT, EPV>::run(hv[i], f);
+            uint32_t pk[EPV / 4];
+#pragma unroll
+            for (int k = 0; k < EPV / 4; ++k)
+                pk[k] = pack4(code_of(f[4 * k], s), code_of(f[4 * k + 1], s), code_of(f[4 * k + 2], s), code_of(f[4 * k + 3], s));
+            if (idx < nvec) store_vec(idx, pk);
+        }
+    }
+}
+
+// generic path: any cols / leading dimensions / alignment.  One block per row; h is recomputed in the second pass.
+template <int DT>
+__global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __restrict__ g, int64_t ldg, const void* __restrict__ u,
+                                                              int64_t ldu, int64_t cols, int8_t* __restrict__ q, int64_t ldq,
+                                                              float* __restrict__ scale, void* __restrict__ h_out, int64_t ldh) {
+    using S = typename Elem<DT>::store_t;
+    const int64_t row = blockIdx.x;
+    const S* gr = reinterpret_cast<const S*>(g) + row * ldg;
+    const S* ur = reinterpret_cast<const S*>(u) + row * ldu;
+    auto h_at = [&](int64_t c) -> S { return Elem<DT>::from_f32(silu_mul_spec<DT>(Elem<DT>::to_f32(gr[c]), Elem<DT>::to_f32(ur[c]))); };
+    float amax = 0.0f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        const S h = h_at(c);
+        if (h_out) reinterpret_cast<S*>(h_out)[row * ldh + c] = h;
+        amax = amax_step(amax, Elem<DT>::to_f32(h));
+    }
+    amax = wave_max(amax);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) amax = part[w] > amax ? part[w] : amax;
+    const float s = scale_of(amax);
+    if (threadIdx.x == 0) scale[row] = s;
+    int8_t* qr = q + row * ldq;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) qr[c] = (int8_t)code_of(Elem<DT>::to_f32(h_at(c)), s);
+}
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+template <int DT, int TPR, bool WRITE_H>
+static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const uint8_t* u, int64_t ldu_b, int64_t rows, int nvec,
+                                int8_t* q, int64_t ldq, float* scale, uint8_t* h, int64_t ldh_b, hipStream_t st) {
+    constexpr int RPB = 256 / TPR;
+    const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
+    switch (vpt) {
+        case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 8: silu_mul_quant_vec<DT, 8, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        default:
+            if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            break;
+    }
+}
+
+template <int DT>
+void silu_mul_quant_dispatch(const void* g, int64_t ldg, const void* u, int64_t ldu, int64_t rows, int64_t cols, int8_t* q,
+                             int64_t ldq, float* scale, void* h_out, int64_t ldh, hipStream_t st) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const bool vec_ok = (cols % EPV == 0) && (ldg % EPV == 0) && (ldu % EPV == 0) && aligned_to(g, 16) && aligned_to(u, 16) &&
+                        (ldq % EPV == 0) && aligned_to(q, EPV) && cols / EPV <= 256 * 16 &&
+                        (!h_out || ((ldh % EPV == 0) && aligned_to(h_out, 16)));
+    if (!vec_ok) {
+        silu_mul_quant_generic<DT><<<dim3((unsigned)rows), dim3(256), 0, st>>>(g, ldg, u, ldu, cols, q, ldq, scale, h_out, ldh);
+        return;
+    }
+    const int nvec = (int)(cols / EPV);
+    auto pow2 = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
+    const uint8_t* gb = reinterpret_cast<const uint8_t*>(g);
+    const uint8_t* ub = reinterpret_cast<const uint8_t*>(u);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(h_out);
+    const int64_t kb = Elem<DT>::kBytes;
+    if (nvec <= 64 * 4) {
+        const int vpt = pow2((nvec + 63) / 64);
+        if (h_out) launch_silu_mul_vec<DT, 64, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
+        else launch_silu_mul_vec<DT, 64, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
+    } else {
+        const int vpt = pow2((nvec + 255) / 256);
+        if (h_out) launch_silu_mul_vec<DT, 256, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
+        else launch_silu_mul_vec<DT, 256, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
+    }
+}
+
+template void silu_mul_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+template void silu_mul_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+template void silu_mul_quant_dispatch<PQ_F32>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+
+}  // namespace pq

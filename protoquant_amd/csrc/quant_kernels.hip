@@ -2,111 +2,9 @@
 // All three are HBM-bound byte movers: 16-byte coalesced loads, one read of x for K1 (the row lives
 // in registers between the amax reduction and the encode), wavefront shuffles + one LDS hop for the
 // reductions.  Arithmetic follows QSPEC v1 exactly (true fp32 division, RNE, no contraction).
-#include "pq_common.h"
+#include "quant_device.h"
 
 namespace pq {
-
-template <int DT, int N> struct Unpack;
-template <> struct Unpack<PQ_BF16, 8> {
-    __device__ static __forceinline__ void run(const v4u& v, float (&f)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-            f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xFFFF0000u);
-        }
-    }
-};
-template <> struct Unpack<PQ_FP16, 8> {
-    __device__ static __forceinline__ void run(const v4u& v, float (&f)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f[2 * i] = Elem<PQ_FP16>::to_f32((uint16_t)(v[i] & 0xFFFFu));
-            f[2 * i + 1] = Elem<PQ_FP16>::to_f32((uint16_t)(v[i] >> 16));
-        }
-    }
-};
-template <> struct Unpack<PQ_F32, 4> {
-    __device__ static __forceinline__ void run(const v4u& v, float (&f)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t u = v[i];   // copy first: bit_cast of a vector-element lvalue reads element 0
-            f[i] = __builtin_bit_cast(float, u);
-        }
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// Exact-result fast encode (QSPEC Q4-Q6 without a division per element).
-//   r = RN(1/s): ONE IEEE division per scale.  Per element the correctly rounded quotient Q = RN(x/s) is
-//   rebuilt with two FMA residual corrections (Markstein: with y = RN(1/b) and q within 1 ulp of a/b,
-//   r = a - b*q is exact and RN(q + r*y) = RN(a/b), unless b's significand is all ones):
-//       q = x*r;  e = fma(-q, s, x);  q = fma(e, r, q);  e = fma(-q, s, x);  q = fma(e, r, q)   ==  x / s
-//   then m = q + 1.5*2^23 rounds q to the nearest-even integer k (= rintf) and leaves k's two's complement
-//   in the low mantissa bits, so the code byte is the low byte of m.  |x| <= amax gives |k| <= 127: no clamp.
-// Valid when 2^-60 < s < 2^60, s's significand is not all ones and the data hold no NaN/Inf
-// (scale_fast_ok + the amax bit test); everything else takes the exact-division path.  The identity is
-// checked by brute force on the GPU in tests/test_gpu_parity.py::test_fast_quotient_bruteforce.
-constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23
-
-__device__ __forceinline__ bool scale_fast_ok(float s) {
-    const uint32_t b = __builtin_bit_cast(uint32_t, s);
-    const uint32_t e = b >> 23;                 // s > 0
-    return e >= 67u && e <= 187u && (b & 0x7FFFFFu) != 0x7FFFFFu;
-}
-__device__ __forceinline__ float quotient_fast(float x, float s, float r) {
-    float q = x * r;
-    float e = __builtin_fmaf(-q, s, x);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-q, s, x);
-    q = __builtin_fmaf(e, r, q);
-    return q;
-}
-// encodes N elements; returns the N code bytes packed little-endian
-template <int N>
-__device__ __forceinline__ void fast_encode(const float (&f)[N], float s, float r, uint32_t (&packed)[N / 4]) {
-    uint32_t mb[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) mb[j] = __builtin_bit_cast(uint32_t, quotient_fast(f[j], s, r) + kMagic);
-#pragma unroll
-    for (int g = 0; g < N / 4; ++g)
-        packed[g] = __builtin_amdgcn_perm(mb[4 * g + 1], mb[4 * g], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * g + 3], mb[4 * g + 2], 0x04000c0cu);
-}
-
-// amax of one 16-byte vector on the raw bit patterns (integer max; NaN patterns sort above Inf and are
-// detected afterwards).  Returns max |x| bits widened to f32 bit patterns.
-template <int DT>
-__device__ __forceinline__ uint32_t vec_amax_bits(const v4u& v, uint32_t cur) {
-    if constexpr (DT == PQ_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const uint32_t a = v[i] & 0x7FFFFFFFu; cur = a > cur ? a : cur; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t a = v[i] & 0x7FFF7FFFu;
-            const uint32_t lo = a & 0xFFFFu, hi = a >> 16;
-            const uint32_t mx = lo > hi ? lo : hi;
-            cur = mx > cur ? mx : cur;
-        }
-    }
-    return cur;
-}
-template <int DT> __device__ __forceinline__ bool amax_bits_has_nan(uint32_t b) {
-    if constexpr (DT == PQ_F32) return b > 0x7F800000u;
-    else if constexpr (DT == PQ_BF16) return b > 0x7F80u;
-    else return b > 0x7C00u;
-}
-template <int DT> __device__ __forceinline__ float amax_bits_to_f32(uint32_t b) {
-    if constexpr (DT == PQ_F32) return __builtin_bit_cast(float, b);
-    else return Elem<DT>::to_f32((uint16_t)b);
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1 vector path.  TPR threads own one row; thread t holds 16-byte vectors t, t+TPR, ... (VPT of

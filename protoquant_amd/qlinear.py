@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .qtensor import QTensor, quantize
+from .qtensor import QTensor, quantize, silu_mul_quantize
 
 
 def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
@@ -139,9 +139,16 @@ class qlinear(nn.Module):
             m.bias = None
         return m
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x) -> torch.Tensor:
+        """x: a float tensor [..., K] (quantised per token here, K1), or a per-token QTensor made by quantize() /
+        silu_mul_quantize() (its codes and scales go straight to the GEMM; output dtype = its orig_dtype)."""
         if x.shape[-1] != self.in_features:
             raise ValueError(f"qlinear: expected last dim {self.in_features}, got {x.shape[-1]}")
+        if isinstance(x, QTensor):
+            if x.axis != 1:
+                raise ValueError("qlinear: a QTensor input must be quantised per token (axis=-1)")
+            y = qlinear_s8(x.int_data.reshape(-1, self.in_features), x.scale, self.wq, self.ws, self.bias, x.orig_dtype)
+            return y.reshape(*x.shape[:-1], self.out_features)
         return qlinear_dyn(x, self.wq, self.ws, self.bias)
 
     def extra_repr(self):
@@ -180,6 +187,26 @@ class FusedQLinear(nn.Module):
         y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, x.dtype)
         y = y.reshape(*x.shape[:-1], self.out_features)
         return torch.split(y, self.splits, dim=-1)
+
+
+class GatedMLP(nn.Module):
+    """The gated MLP block of BASELINE config 3 on the int8 path: down(silu(gate(x)) * up(x)).
+    gate and up share one activation quantisation and one GEMM launch (FusedQLinear); silu*mul is fused into the
+    quantisation of down's input (silu_mul_quantize), so between the two GEMMs only int8 codes + row scales exist."""
+
+    def __init__(self, gate_up: FusedQLinear, down: qlinear):
+        super().__init__()
+        if len(gate_up.splits) != 2 or gate_up.splits[0] != gate_up.splits[1] or gate_up.splits[0] != down.in_features:
+            raise ValueError("GatedMLP: gate and up must both map to down.in_features")
+        self.gate_up, self.down = gate_up, down
+
+    @classmethod
+    def from_linears(cls, gate: nn.Linear, up: nn.Linear, down: nn.Linear) -> "GatedMLP":
+        return cls(FusedQLinear.from_linears(gate, up), qlinear.from_linear(down))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        g, u = self.gate_up(x)
+        return self.down(silu_mul_quantize(g, u))
 
 
 def swap_linears(model: nn.Module, predicate=None) -> nn.Module:

@@ -71,6 +71,39 @@ def quantize(x: torch.Tensor, axis: int = -1) -> QTensor:
     return QTensor(q.reshape(x.shape), scale, red, x.dtype, x.shape)
 
 
+def _rows_view(t: torch.Tensor) -> torch.Tensor:
+    """[..., C] -> a 2-D [rows, C] view with unit column stride (column slices of a wider matrix stay views)."""
+    lead = 1
+    for d in t.shape[:-1]:
+        lead *= d
+    t2 = t if t.dim() == 2 else t.reshape(lead, t.shape[-1])
+    return L.row_major_2d(t2)
+
+
+def silu_mul_quantize(g: torch.Tensor, u: torch.Tensor, return_h: bool = False):
+    """quantize(F.silu(g) * u, axis=-1) in ONE pass (kernel K1 fused into its producer): the activation of a gated
+    MLP's down projection is computed, reduced and encoded in registers and never goes to HBM in bf16.
+    g and u may be column slices of one fused gate+up output.  Numerics: QSPEC S1-S6 then Q1-Q6.
+    return_h=True also returns h = silu(g)*u in the input dtype (stored by the same kernel)."""
+    L.require_gpu(g, "silu_mul_quantize(g)")
+    L.require_gpu(u, "silu_mul_quantize(u)")
+    if g.shape != u.shape or g.dtype != u.dtype or g.device != u.device or g.dim() < 1:
+        raise ValueError(f"silu_mul_quantize: g {tuple(g.shape)} {g.dtype} and u {tuple(u.shape)} {u.dtype} must match")
+    code = L.dtype_code(g.dtype)
+    g2, u2 = _rows_view(g), _rows_view(u)
+    rows, cols = g2.shape
+    q = torch.empty((rows, cols), dtype=torch.int8, device=g.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=g.device)
+    h = torch.empty((rows, cols), dtype=g.dtype, device=g.device) if return_h else None
+    with torch.cuda.device(g.device):
+        L.check(L.lib().pq_silu_mul_quant_rowwise(g2.data_ptr(), L.ld(g2), u2.data_ptr(), L.ld(u2), code, rows, cols,
+                                                  q.data_ptr(), max(cols, 1), scale.data_ptr(),
+                                                  h.data_ptr() if return_h else None, max(cols, 1), L.stream_ptr(g)),
+                "silu_mul_quantize")
+    qt = QTensor(q.reshape(g.shape), scale, 1, g.dtype, g.shape)
+    return (qt, h.reshape(g.shape)) if return_h else qt
+
+
 def dequantize(q: QTensor, dtype: torch.dtype | None = None) -> torch.Tensor:
     """cast_rne(f32(int_data) * scale) along the kept axis -> `dtype` (default: the original dtype)."""
     dtype = dtype or q.orig_dtype

@@ -30,3 +30,14 @@ def load_golden(path):
 @pytest.fixture(params=GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def golden(request):
     return load_golden(request.param)
+
+
+PRODUCER_GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "producer", "*.npz")))
+
+
+@pytest.fixture(params=PRODUCER_GOLDEN, ids=[os.path.basename(p)[:-4] for p in PRODUCER_GOLDEN])
+def producer_golden(request):
+    z = np.load(request.param)
+    d = {k: z[k] for k in z.files}
+    d["code"] = int(d["code"])
+    return d

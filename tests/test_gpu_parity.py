@@ -463,6 +463,108 @@ def test_full_size_cfg3_mlp_block(pq):
     same(qh.int_data, hq, "hq cfg3"); same(qh.scale, hs, "hs cfg3")
 
 
+# ---------------------------------------------------------------- producer-fused quantisation (QSPEC S1-S6)
+def _same_h(got, want, code, what):
+    """h parity: NaNs as a class (payloads are not specified), everything else bit for bit"""
+    gb = bits(got); wb = np.asarray(want)
+    wb = wb.view(np.uint32) if wb.dtype == np.float32 else wb
+    nan = np.isnan(Q.to_f32(want, code))
+    assert np.array_equal(np.isnan(got.float().cpu().numpy()), nan), what + ": NaN positions"
+    bad = int(np.count_nonzero(gb[~nan] != wb[~nan]))
+    assert bad == 0, f"{what}: {bad} elements differ"
+
+
+def test_golden_silu_mul_quantize(pq, producer_golden):
+    g = producer_golden
+    code = g["code"]
+    qt, h = pq.silu_mul_quantize(to_gpu(g["g"], code), to_gpu(g["u"], code), return_h=True)
+    same(qt.int_data, g["q"], "silu q"); same(qt.scale, g["scale"], "silu scale")
+    _same_h(h, g["h"], code, "silu h")
+    qt2 = pq.silu_mul_quantize(to_gpu(g["g"], code), to_gpu(g["u"], code))
+    same(qt2.int_data, g["q"], "silu q (no h)"); same(qt2.scale, g["scale"], "silu scale (no h)")
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (7, 13), (33, 1000), (64, 4096), (5, 11008), (3, 28672), (2, 40000), (300, 512),
+                                       (1, 8), (130, 2048), (2, 65536 + 8)])
+def test_silu_mul_quant_vs_oracle(pq, code, rows, cols):
+    """Vector path (16-byte aligned widths up to 4096 vectors) and generic path (ragged / very wide), g and u as the two
+    column halves of ONE [rows, 2*cols] matrix (how a fused gate+up GEMM hands them over) and as separate tensors."""
+    rng = np.random.default_rng(rows * 131 + cols + code)
+    gu = Q.from_f32((rng.standard_normal((rows, 2 * cols)) * 2.5).astype(np.float32), code)
+    gu_t = to_gpu(gu, code)
+    want_q, want_s, want_h = C.silu_mul_quant_rowwise(gu[:, :cols], gu[:, cols:], code)
+    qt, h = pq.silu_mul_quantize(gu_t[:, :cols], gu_t[:, cols:], return_h=True)
+    same(qt.int_data, want_q, "q (halves)"); same(qt.scale, want_s, "scale (halves)"); _same_h(h, want_h, code, "h (halves)")
+    qt = pq.silu_mul_quantize(gu_t[:, :cols].contiguous(), gu_t[:, cols:].contiguous())
+    same(qt.int_data, want_q, "q (separate)"); same(qt.scale, want_s, "scale (separate)")
+    # == the two-step product path on the same h: quantize(h)
+    q2 = pq.quantize(h)
+    same(q2.int_data, want_q, "quantize(h)"); same(q2.scale, want_s, "quantize(h) scale")
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+def test_silu_fast_division_equals_ieee_division(pq, code):
+    """The vector path divides without v_div_scale/fixup when every |g| of a wave is in (0, 86]; the generic path (taken
+    here by shifting the same data one element, which breaks the 16-byte alignment) always uses `/`.  Same h, bit for bit,
+    on 8M random gate values spread over the whole safe range, incl. its edges and sub-2^-25 magnitudes."""
+    rng = np.random.default_rng(77 + code)
+    rows, cols = 2048, 4096
+    mag = np.exp(rng.uniform(np.log(1e-30), np.log(86.0), (rows, cols)))
+    mag[:, :16] = np.array([86.0, 85.99, 1e-38, 2.0**-25, 2.0**-24, 1.0, 17.3, 60.0, 6e-8 if code == 1 else 1e-30, 0.5, 3.0, 10.0, 44.0, 80.0, 87.9, 2.0**-100])
+    g = (mag * rng.choice([-1.0, 1.0], (rows, cols))).astype(np.float32)
+    u = rng.standard_normal((rows, cols)).astype(np.float32)
+    gs, us = to_gpu(Q.from_f32(g, code), code), to_gpu(Q.from_f32(u, code), code)
+    pad = torch.zeros((rows, cols + 8), dtype=gs.dtype, device="cuda"); pad2 = torch.zeros_like(pad)
+    pad[:, 1:cols + 1] = gs; pad2[:, 1:cols + 1] = us
+    qa, ha = pq.silu_mul_quantize(gs, us, return_h=True)                                    # vector path
+    qb, hb = pq.silu_mul_quantize(pad[:, 1:cols + 1], pad2[:, 1:cols + 1], return_h=True)  # generic path
+    assert torch.equal(ha.view(torch.int32 if code == 2 else torch.int16), hb.view(torch.int32 if code == 2 else torch.int16))
+    assert torch.equal(qa.int_data, qb.int_data) and torch.equal(qa.scale, qb.scale)
+    # and a sample of rows against the oracle
+    want_q, want_s, want_h = C.silu_mul_quant_rowwise(bits(gs[:64]), bits(us[:64]), code)
+    same(qa.int_data[:64], want_q, "q"); same(qa.scale[:64], want_s, "scale"); _same_h(ha[:64], want_h, code, "h")
+
+
+def test_silu_mul_quantize_3d_and_errors(pq):
+    g = torch.randn(2, 5, 64, device="cuda", dtype=torch.bfloat16); u = torch.randn(2, 5, 64, device="cuda", dtype=torch.bfloat16)
+    qt = pq.silu_mul_quantize(g, u)
+    assert qt.int_data.shape == (2, 5, 64) and qt.scale.shape == (10,) and qt.axis == 1
+    want_q, want_s, _ = C.silu_mul_quant_rowwise(bits(g).reshape(10, 64), bits(u).reshape(10, 64), 0)
+    same(qt.int_data.reshape(10, 64), want_q, "3d q"); same(qt.scale, want_s, "3d scale")
+    with pytest.raises(ValueError):
+        pq.silu_mul_quantize(g, u[:, :, :32])
+    with pytest.raises(Exception):
+        pq.silu_mul_quantize(g.cpu(), u.cpu())
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    st = L.pq_silu_mul_quant_rowwise(g.data_ptr(), 32, u.data_ptr(), 64, 0, 10, 64, qt.int_data.data_ptr(), 64, qt.scale.data_ptr(), None, 0, None)
+    assert st == 1 and b"pq_silu_mul_quant_rowwise" in L.pq_last_error()
+
+
+def test_gated_mlp_matches_oracle_pipeline(pq):
+    """GatedMLP (fused gate+up GEMM -> silu_mul_quantize -> down GEMM) vs the oracle pipeline, bit for bit, and within
+    int8 noise of the float block."""
+    M, H, I = 192, 256, 640
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(M, H, generator=gen).to(torch.bfloat16)
+    lins = {n: torch.nn.Linear(i, o, bias=False, dtype=torch.bfloat16) for n, (o, i) in (("gate", (I, H)), ("up", (I, H)), ("down", (H, I)))}
+    with torch.no_grad():
+        for l in lins.values():
+            l.weight.copy_((torch.randn(l.weight.shape, generator=gen) * 0.05).to(torch.bfloat16))
+    import copy
+    mlp = pq.GatedMLP.from_linears(*(copy.deepcopy(lins[n]).cuda() for n in ("gate", "up", "down")))
+    y = mlp(x.cuda())
+    wq = {n: C.quant_rowwise(bits(l.weight), 0) for n, l in lins.items()}
+    xq, xs = C.quant_rowwise(bits(x), 0)
+    gate = C.qlinear_s8(xq, xs, *wq["gate"], None, 0); up = C.qlinear_s8(xq, xs, *wq["up"], None, 0)
+    hq, hs, _ = C.silu_mul_quant_rowwise(gate, up, 0)
+    same(y, C.qlinear_s8(hq, hs, *wq["down"], None, 0), "GatedMLP y")
+    ref = lins["down"].float()(torch.nn.functional.silu(lins["gate"].float()(x.float())) * lins["up"].float()(x.float()))
+    rel = float((y.float().cpu() - ref).norm() / ref.norm())
+    assert rel < 0.03, rel
+
+
 def test_randomized_shape_sweep(pq):
     """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
     arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""

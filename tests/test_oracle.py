@@ -119,3 +119,75 @@ def test_quantize_properties_hypothesis(xf, dtype):
             assert np.all(np.abs(xr - q.astype(np.float32) * se) <= se * 0.5 * (1 + 1e-6) + 1e-30)
             zero = (np.abs(xr).max(axis=axis) == 0)
             assert np.all(s[zero] == 1.0)
+
+
+# ---------------------------------------------------------------- producer-fused quantisation (QSPEC S1-S6)
+def eq_nan(a, b):
+    """bit equality, NaNs compared as a class (payloads are not part of the spec)"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    if a.dtype == np.float32:
+        na, nb = np.isnan(a), np.isnan(b)
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    else:
+        na, nb = np.zeros(a.shape, bool), np.zeros(b.shape, bool)
+    assert np.array_equal(na, nb)
+    assert np.array_equal(a[~na], b[~nb]), f"{np.count_nonzero(a[~na] != b[~nb])} of {a.size} differ"
+
+
+def _nan_mask(h, code):
+    return np.isnan(Q.to_f32(h, code))
+
+
+def test_silu_mul_quant_oracles_match_golden(producer_golden):
+    g = producer_golden
+    code = g["code"]
+    for impl in (Q.silu_mul_quantize, C.silu_mul_quant_rowwise):
+        q, s, h = impl(g["g"], g["u"], code)
+        eq(q, g["q"]); eq(s, g["scale"])
+        nan = _nan_mask(g["h"], code)
+        assert np.array_equal(_nan_mask(h, code), nan)
+        assert np.array_equal(np.asarray(h)[~nan].view(np.uint8), g["h"][~nan].view(np.uint8))
+
+
+def test_silu_spec_stays_close_to_torch_eager(producer_golden):
+    """The specified exponential is within 1 ulp of exp: against torch's eager F.silu(g)*u the stored product may
+    differ by one storage-ulp on a small fraction of elements (none at all for the 16-bit types on these inputs;
+    up to 2 ulp in fp32, where torch's own exp carries its ulp too)."""
+    g = producer_golden
+    code = g["code"]
+    h, t = Q.to_f32(g["h"], code).astype(np.float64), Q.to_f32(g["h_torch"], code).astype(np.float64)
+    ok = np.isfinite(h) & np.isfinite(t)
+    assert np.array_equal(np.isnan(h), np.isnan(t))
+    diff = h[ok] != t[ok]
+    assert diff.mean() <= (0.06 if code == 2 else 0.001)
+    ulp = np.spacing(np.abs(t[ok]).astype(np.float32)).astype(np.float64) * {0: 2.0**16, 1: 2.0**13, 2: 1.0}[code]
+    assert np.all(np.abs(h[ok] - t[ok]) <= (2.01 if code == 2 else 1.01) * np.maximum(ulp, 1e-45))
+
+
+def test_exp_spec_accuracy_and_agreement():
+    rng = np.random.default_rng(5)
+    t = np.concatenate([rng.uniform(-110, 110, 20000), rng.standard_normal(20000) * 5,
+                        [0, -0.0, 88.7, 88.8, 100, 200, -17, -30, -31, -200, np.inf, -np.inf, np.nan, 1e-40]]).astype(np.float32)
+    a, b = Q.exp_spec(t), C.exp_spec(t)
+    eq_nan(a, b)
+    ref = np.exp(np.maximum(t.astype(np.float64), -30.0))
+    ok = np.isfinite(ref) & (ref < 3e38) & ~np.isnan(t)
+    err = np.abs(a[ok].astype(np.float64) - ref[ok]) / np.spacing(ref[ok].astype(np.float32)).astype(np.float64)
+    assert err.max() < 1.0
+
+
+def test_fma32_emulation_is_exact():
+    """oracle/qspec_numpy.fma32 against exact rational arithmetic, including binary32 ties of the 53-bit sum."""
+    from fractions import Fraction
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal(3000).astype(np.float32); b = rng.standard_normal(3000).astype(np.float32)
+    c = (-(a.astype(np.float64) * b.astype(np.float64))).astype(np.float32) + rng.standard_normal(3000).astype(np.float32) * 1e-6
+    a = np.concatenate([a, np.float32([1 + 2**-12, 1 + 2**-23, 3])]); b = np.concatenate([b, np.float32([1 + 2**-12, 1 - 2**-23, 2**-25])])
+    c = np.concatenate([c, np.float32([2**-60, 2**-80, 1])])
+    got = Q.fma32(a, b, c)
+    for i in range(a.size):
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        lo = np.float32(got[i]); cands = [np.nextafter(lo, np.float32(-np.inf)), lo, np.nextafter(lo, np.float32(np.inf))]
+        best = min(cands, key=lambda v: (abs(Fraction(float(v)) - exact), int(np.float32(v).view(np.uint32)) & 1))
+        assert np.float32(best) == lo, (i, a[i], b[i], c[i])
