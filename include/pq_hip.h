@@ -66,6 +66,15 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
                                   int64_t rows, int64_t cols, int8_t* q, int64_t ld_q, float* scale,
                                   void* h_out, int64_t ld_h, void* stream);
 
+/* K1 fused into RMSNorm: quantize(weight * (x.float() * rsqrt(mean(x.float()^2) + eps)).to(dtype)) per
+ * token in one pass — the input of the q/k/v and gate/up projections of a decoder layer.  x: [rows, cols], weight: [cols],
+ * both of `dtype`; h_out (nullable, ld_h): also store the normalised activation.  Numerics: QSPEC N1-N6 — the sum of squares
+ * is reduced in a pinned order (16-byte vectors dealt to 256 lanes, xor butterfly per 64 lanes, four partial sums left to
+ * right), IEEE sqrt and division, storage rounding after x*rs and after the weight product — then Q1-Q6.  cols < 2^24. */
+int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight, float eps, int32_t dtype,
+                                 int64_t rows, int64_t cols, int8_t* q, int64_t ld_q, float* scale,
+                                 void* h_out, int64_t ld_h, void* stream);
+
 /* dequantize(): out[r,c] = cast_rne(f32(q[r,c]) * scale[axis==0 ? c : r]).  `axis` is the axis the
  * scale was reduced over (1: one scale per row, 0: one scale per column).   QSPEC D1. */
 int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis,

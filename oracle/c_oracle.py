@@ -105,3 +105,16 @@ def silu_mul_quant_rowwise(g: np.ndarray, u: np.ndarray, dtype: int, want_h: boo
     h = np.zeros((r, c), _store(dtype)) if want_h else None
     lib().oq_silu_mul_quant_rowwise(_p(g), i64(c), _p(u), i64(c), dtype, i64(r), i64(c), _p(q), i64(c), _p(s), _p(h), i64(c))
     return q, s, h
+
+
+def rmsnorm_quant_rowwise(x: np.ndarray, weight: np.ndarray, eps: float, dtype: int, want_h: bool = True):
+    """QSPEC N1-N6.  x: [rows, cols], weight: [cols], stored dtype.  Returns (q, scale, h or None, rs)."""
+    x = np.ascontiguousarray(x); weight = np.ascontiguousarray(weight)
+    r, c = x.shape
+    q = np.zeros((r, c), np.int8)
+    s = np.zeros(r, np.float32)
+    rs = np.zeros(r, np.float32)
+    h = np.zeros((r, c), _store(dtype)) if want_h else None
+    lib().oq_rmsnorm_quant_rowwise(_p(x), i64(c), _p(weight), ctypes.c_float(eps), dtype, i64(r), i64(c), _p(q), i64(c), _p(s),
+                                   _p(h), i64(c), _p(rs))
+    return q, s, h, rs

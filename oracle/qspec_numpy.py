@@ -162,3 +162,38 @@ def silu_mul_quantize(g: np.ndarray, u: np.ndarray, dtype):
     h = silu_mul(g, u, dtype)
     q, s = quantize(h, dtype, 1)
     return q, s, h
+
+
+# ---------------------------------------------------------------- QSPEC N1-N6: RMSNorm -> per-token quantisation
+def rms_sumsq(xf: np.ndarray, epv: int) -> np.ndarray:
+    """N1-N3: the pinned-order sum of squares of each row of xf (float32 [rows, cols])."""
+    rows, cols = xf.shape
+    nvec = (cols + epv - 1) // epv
+    slots = (nvec + 255) // 256                       # vectors per lane
+    pad = np.zeros((rows, slots * 256 * epv), np.float32)
+    pad[:, :cols] = xf                                # zero padding adds fma(0, 0, acc) = acc: no effect
+    v = pad.reshape(rows, slots, 256, epv)            # [row, i, lane, e]: vector i*256 + lane
+    acc = np.zeros((rows, 256), np.float32)
+    for i in range(slots):
+        for e in range(epv):
+            acc = fma32(v[:, i, :, e], v[:, i, :, e], acc)
+    s = acc.reshape(rows, 4, 64)
+    lanes = np.arange(64)
+    for off in (32, 16, 8, 4, 2, 1):
+        s = (s + s[:, :, lanes ^ off]).astype(np.float32)
+    g = s[:, :, 0]
+    return (((g[:, 0] + g[:, 1]).astype(np.float32) + g[:, 2]).astype(np.float32) + g[:, 3]).astype(np.float32)
+
+
+def rmsnorm_quantize(x: np.ndarray, weight: np.ndarray, eps: float, dtype):
+    """QSPEC N1-N6.  Returns (q int8, scale f32, h stored dtype, rs f32)."""
+    d = dt(dtype)
+    xf, wf = to_f32(x, d), to_f32(weight, d)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        ss = rms_sumsq(xf, 4 if d == DT_F32 else 8)
+        var = (ss / np.float32(xf.shape[1])).astype(np.float32)
+        rs = (np.float32(1) / np.sqrt((var + np.float32(eps)).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        xn = to_f32(from_f32((xf * rs[:, None]).astype(np.float32), d), d)
+        h = from_f32((wf[None, :] * xn).astype(np.float32), d)
+    q, s = quantize(h, d, 1)
+    return q, s, h, rs

@@ -207,3 +207,71 @@ void oq_silu_mul_quant_rowwise(const void* g, int64_t ldg, const void* u, int64_
         }
     }
 }
+
+/* ---- QSPEC N1-N6: RMSNorm(x; weight, eps) -> per-token quantisation, the producer-fused form of
+ *      quantize(weight * (x.float() * rsqrt(mean(x.float()^2) + eps)).to(dtype))     
+ * The sum of squares is a float reduction, so its ORDER is part of the specification (any fixed order is as accurate
+ * as any other; pinning one makes every implementation agree bit for bit):
+ *   N1  the row is cut into 16-byte vectors of EPV = 16/sizeof(dtype) elements; vector v belongs to lane v mod 256
+ *   N2  each lane accumulates its vectors in increasing v, elements in increasing index:  acc = fma(x, x, acc)
+ *   N3  lanes combine inside each group of 64 by an xor butterfly (offsets 32,16,8,4,2,1: s = s + s[lane ^ off]),
+ *       then the four group sums left to right:  ss = ((s0 + s1) + s2) + s3
+ *   N4  var = ss / f32(C);   rs = 1 / sqrt(var + eps)          (IEEE sqrt and division)
+ *   N5  xn = cast(f32(x) * rs);   h = cast(f32(weight) * f32(xn))   (storage rounding after each, as the eager ops do)
+ *   N6  Q1-Q6 on the rows of h */
+static float rms_sumsq_spec(const void* x, int dtype, int64_t base, int64_t cols) {
+    const int epv = dtype == OQ_F32 ? 4 : 8;
+    float lane[256];
+    for (int l = 0; l < 256; ++l) lane[l] = 0.0f;
+    const int64_t nvec = (cols + epv - 1) / epv;
+    for (int64_t v = 0; v < nvec; ++v) {
+        float acc = lane[v & 255];
+        for (int e = 0; e < epv && v * epv + e < cols; ++e) {
+            const float xv = load_f32(x, dtype, base + v * epv + e);
+            acc = fmaf(xv, xv, acc);
+        }
+        lane[v & 255] = acc;
+    }
+    float grp[4];
+    for (int gidx = 0; gidx < 4; ++gidx) {
+        float s[64], t[64];
+        for (int l = 0; l < 64; ++l) s[l] = lane[gidx * 64 + l];
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ off];
+            for (int l = 0; l < 64; ++l) s[l] = t[l];
+        }
+        grp[gidx] = s[0];
+    }
+    return ((grp[0] + grp[1]) + grp[2]) + grp[3];
+}
+
+static inline float round_store(float v, int dtype) {
+    if (dtype == OQ_BF16) return bf16_to_f32(f32_to_bf16(v));
+    if (dtype == OQ_FP16) return fp16_to_f32(f32_to_fp16(v));
+    return v;
+}
+
+/* x[rows, cols] (ld ldx), weight[cols], both of `dtype`; h_out nullable; rs_out nullable (rows floats, for tests). */
+void oq_rmsnorm_quant_rowwise(const void* x, int64_t ldx, const void* weight, float eps, int dtype, int64_t rows, int64_t cols,
+                              int8_t* q, int64_t ldq, float* scale, void* h_out, int64_t ldh, float* rs_out) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const float ss = rms_sumsq_spec(x, dtype, r * ldx, cols);
+        const float var = ss / (float)cols;
+        const float rs = 1.0f / sqrtf(var + eps);
+        if (rs_out) rs_out[r] = rs;
+        float amax = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            const float s = scale_of(amax);
+            if (pass == 1) scale[r] = s;
+            for (int64_t c = 0; c < cols; ++c) {
+                const float xn = round_store(load_f32(x, dtype, r * ldx + c) * rs, dtype);
+                const float h = round_store(load_f32(weight, dtype, c) * xn, dtype);
+                if (pass == 0) {
+                    amax = amax_step(amax, h);
+                    if (h_out) store_f32(h_out, dtype, r * ldh + c, h);
+                } else q[r * ldq + c] = code_of(h, s);
+            }
+        }
+    }
+}

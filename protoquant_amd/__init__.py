@@ -1,9 +1,9 @@
 """protoquant_amd — MI355X-native dynamic-int8 linear path behind the protoquant Python surface
 (QTensor, quantize(), dequantize(), qlinear).  Hot path = hand-written HIP (gfx950) in
 libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eager fallback."""
-from .qtensor import QTensor, quantize, dequantize, silu_mul_quantize
+from .qtensor import QTensor, quantize, dequantize, silu_mul_quantize, rmsnorm_quantize
 from .qlinear import qlinear, qlinear_s8, qlinear_dyn, int_mm, swap_linears, FusedQLinear, GatedMLP
 from .sharded import ColumnShardedQLinear, RcclColumnGather, gather_columns, shard_bounds
 
-__all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "qlinear_dyn", "int_mm", "swap_linears", "FusedQLinear", "GatedMLP", "silu_mul_quantize",
+__all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "qlinear_dyn", "int_mm", "swap_linears", "FusedQLinear", "GatedMLP", "silu_mul_quantize", "rmsnorm_quantize",
            "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds"]

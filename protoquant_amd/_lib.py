@@ -19,6 +19,7 @@ EXPORTS = (
     "pq_version", "pq_last_error", "pq_quant_rowwise", "pq_quant_colwise", "pq_dequant",
     "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes", "pq_gemm_variant_name",
     "pq_selftest_fast_quotient", "pq_qlinear_dyn", "pq_qlinear_dyn_workspace_bytes", "pq_silu_mul_quant_rowwise",
+    "pq_rmsnorm_quant_rowwise",
 )
 
 _lib = None
@@ -61,6 +62,8 @@ def lib() -> ctypes.CDLL:
     L.pq_qlinear_dyn.argtypes = [vp, i32, i64, vp, i64, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp]
     L.pq_silu_mul_quant_rowwise.restype = i32
     L.pq_silu_mul_quant_rowwise.argtypes = [vp, i64, vp, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp]
+    L.pq_rmsnorm_quant_rowwise.restype = i32
+    L.pq_rmsnorm_quant_rowwise.argtypes = [vp, i64, vp, ctypes.c_float, i32, i64, i64, vp, i64, vp, vp, i64, vp]
     L.pq_selftest_fast_quotient.restype = i32
     L.pq_selftest_fast_quotient.argtypes = [vp, vp, i64, vp, vp]
     if L.pq_version() != ABI_VERSION:

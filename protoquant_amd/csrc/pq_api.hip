@@ -11,6 +11,7 @@ namespace pq {
 template <int DT> void quant_rowwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template <int DT> void quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template <int DT> void silu_mul_quant_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE, int TM> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
@@ -181,6 +182,27 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
         default: pq::silu_mul_quant_dispatch<PQ_F32>(g, ld_g, u, ld_u, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
     }
     return check_launch("pq_silu_mul_quant_rowwise");
+}
+
+int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight, float eps, int32_t dtype, int64_t rows, int64_t cols,
+                                 int8_t* q, int64_t ld_q, float* scale, void* h_out, int64_t ld_h, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_rmsnorm_quant_rowwise: unknown dtype %d", dtype);
+    if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale) || (rows > 0 && cols > 0 && !weight) ||
+        (h_out && ld_h < cols) || cols >= (1 << 24) || !(eps >= 0.0f))
+        return fail(PQ_ERR_BAD_ARG, "pq_rmsnorm_quant_rowwise: bad arguments (rows=%lld cols=%lld ld_x=%lld ld_q=%lld ld_h=%lld eps=%g)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q, (long long)ld_h, (double)eps);
+    if (rows == 0) return PQ_OK;
+    if (cols == 0) {       // nothing to normalise: scale = 1 (QSPEC Q3), no codes
+        hipStream_t st0 = static_cast<hipStream_t>(stream);
+        pq::quant_rowwise_dispatch<PQ_F32>(x, rows, 0, 1, q, 1, scale, st0);
+        return check_launch("pq_rmsnorm_quant_rowwise");
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::rmsnorm_quant_dispatch<PQ_BF16>(x, ld_x, weight, eps, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+        case PQ_FP16: pq::rmsnorm_quant_dispatch<PQ_FP16>(x, ld_x, weight, eps, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+        default: pq::rmsnorm_quant_dispatch<PQ_F32>(x, ld_x, weight, eps, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
+    }
+    return check_launch("pq_rmsnorm_quant_rowwise");
 }
 
 int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis, int64_t rows, int64_t cols,

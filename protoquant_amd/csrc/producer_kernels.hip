@@ -1,5 +1,7 @@
-// producer_kernels.hip — K1 fused into the elementwise op that produces the activation:
-//   silu(g) * u  ->  per-token int8 codes + row scales, without the bf16 activation ever going to HBM.
+// producer_kernels.hip — K1 fused into the op that produces the activation:
+//   silu(g) * u           ->  per-token int8 codes + row scales   (K1s: the `down` input of a gated MLP)
+//   RMSNorm(x; weight)    ->  per-token int8 codes + row scales   (K1n: the q/k/v and gate/up input of a decoder layer)
+// without the bf16 activation ever going to HBM.
 // Same skeleton as K1 (quant_kernels.hip): TPR threads own a row, the row of h lives in registers between the amax
 // reduction and the encode; here it is COMPUTED from one 16-byte vector of g and one of u per slot instead of loaded.
 // Arithmetic follows QSPEC S1-S6: a specified exponential (Cody-Waite + degree-7 Horner with fma),
@@ -188,50 +190,13 @@ __device__ __forceinline__ void fast_encode_vec(const v4u& hv, float s, float r,
         pk[k] = __builtin_amdgcn_perm(mb[4 * k + 1], mb[4 * k], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * k + 3], mb[4 * k + 2], 0x04000c0cu);
 }
 
-template <int DT, int VPT, int TPR, bool WRITE_H>
-__global__ __launch_bounds__(256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
-                                                          const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
-                                                          int nvec, int8_t* __restrict__ q, int64_t ldq,
-                                                          float* __restrict__ scale, uint8_t* __restrict__ h_out,
-                                                          int64_t ldh_bytes) {
+// The second half of K1, shared by the producer-fused kernels: row amax of the h vectors held in registers (bit-pattern
+// max, NaN-ignoring float pass when a NaN is present), scale, and the division-free exact encode (or the true-division
+// path for NaN/Inf data and extreme scales).  TPR threads own the row; t = thread's index in the row.
+template <int DT, int VPT, int TPR>
+__device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t ab, int t, int nvec, bool active, int64_t row,
+                                                  int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
-    constexpr int RPB = 256 / TPR;
-    const int t = threadIdx.x % TPR;
-    int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
-    const bool active = row < rows;
-    row = active ? row : rows - 1;
-    const uint8_t* gr = g + row * ldg_bytes;
-    const uint8_t* ur = u + row * ldu_bytes;
-
-    // every load is issued before the first use (clamped addresses: a duplicate of the tail vector changes no max)
-    v4u gv[VPT], uv[VPT];
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int idx = i * TPR + t;
-        const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
-        gv[i] = *reinterpret_cast<const v4u*>(gr + off);
-        uv[i] = *reinterpret_cast<const v4u*>(ur + off);
-    }
-    v4u hv[VPT];
-    uint32_t ab = 0;
-    uint32_t gmn = 0xFFFFFFFFu, gmx = 0u;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) vec_absminmax_bits<DT>(gv[i], gmn, gmx);
-    const bool fast_div = __builtin_amdgcn_ballot_w64(!silu_fast_div_ok<DT>(gmn, gmx)) == 0ull;   // wave-uniform
-    auto produce = [&](auto fast) {
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = i * TPR + t;
-            // slots past the row's end (whole waves of them when the width is not VPT * TPR vectors) skip the arithmetic
-            hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
-            ab = vec_amax_bits<DT>(hv[i], ab);
-            if constexpr (WRITE_H) {
-                if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
-            }
-        }
-    };
-    if (fast_div) produce(std::true_type{});
-    else produce(std::false_type{});
     ab = wave_max_u32(ab);
     __shared__ uint32_t part[256 / kWave];
     if constexpr (TPR > kWave) {
@@ -292,6 +257,52 @@ __global__ __launch_bounds__(256) void silu_mul_quant_vec(const uint8_t* __restr
     }
 }
 
+template <int DT, int VPT, int TPR, bool WRITE_H>
+__global__ __launch_bounds__(256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
+                                                          const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
+                                                          int nvec, int8_t* __restrict__ q, int64_t ldq,
+                                                          float* __restrict__ scale, uint8_t* __restrict__ h_out,
+                                                          int64_t ldh_bytes) {
+    constexpr int RPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const bool active = row < rows;
+    row = active ? row : rows - 1;
+    const uint8_t* gr = g + row * ldg_bytes;
+    const uint8_t* ur = u + row * ldu_bytes;
+
+    // every load is issued before the first use (clamped addresses: a duplicate of the tail vector changes no max)
+    v4u gv[VPT], uv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = i * TPR + t;
+        const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
+        gv[i] = *reinterpret_cast<const v4u*>(gr + off);
+        uv[i] = *reinterpret_cast<const v4u*>(ur + off);
+    }
+    v4u hv[VPT];
+    uint32_t ab = 0;
+    uint32_t gmn = 0xFFFFFFFFu, gmx = 0u;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) vec_absminmax_bits<DT>(gv[i], gmn, gmx);
+    const bool fast_div = __builtin_amdgcn_ballot_w64(!silu_fast_div_ok<DT>(gmn, gmx)) == 0ull;   // wave-uniform
+    auto produce = [&](auto fast) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = i * TPR + t;
+            // slots past the row's end (whole waves of them when the width is not VPT * TPR vectors) skip the arithmetic
+            hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
+            ab = vec_amax_bits<DT>(hv[i], ab);
+            if constexpr (WRITE_H) {
+                if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+            }
+        }
+    };
+    if (fast_div) produce(std::true_type{});
+    else produce(std::false_type{});
+    reduce_and_encode<DT, VPT, TPR>(hv, ab, t, nvec, active, row, q, ldq, scale);
+}
+
 // generic path: any cols / leading dimensions / alignment.  One block per row; h is recomputed in the second pass.
 template <int DT>
 __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __restrict__ g, int64_t ldg, const void* __restrict__ u,
@@ -302,6 +313,118 @@ __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __rest
     const S* gr = reinterpret_cast<const S*>(g) + row * ldg;
     const S* ur = reinterpret_cast<const S*>(u) + row * ldu;
     auto h_at = [&](int64_t c) -> S { return Elem<DT>::from_f32(silu_mul_spec<DT>(Elem<DT>::to_f32(gr[c]), Elem<DT>::to_f32(ur[c]))); };
+    float amax = 0.0f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        const S h = h_at(c);
+        if (h_out) reinterpret_cast<S*>(h_out)[row * ldh + c] = h;
+        amax = amax_step(amax, Elem<DT>::to_f32(h));
+    }
+    amax = wave_max(amax);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) amax = part[w] > amax ? part[w] : amax;
+    const float s = scale_of(amax);
+    if (threadIdx.x == 0) scale[row] = s;
+    int8_t* qr = q + row * ldq;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) qr[c] = (int8_t)code_of(Elem<DT>::to_f32(h_at(c)), s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1n: RMSNorm fused into the per-token quantisation (QSPEC N1-N6).  One row per 256-thread block (the reduction order N1-N3
+// IS this layout: vector v on lane v mod 256, xor butterfly per 64 lanes, the four wave sums left to right).  Reads x once
+// (2 B/elem) and the weight vector from L2, writes 1 B/elem + 4 B/row: the normalised bf16 activation never goes to HBM.
+__device__ __forceinline__ float rms_block_sum(float acc) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+__device__ __forceinline__ float rms_rs(float ss, int cols, float eps) {
+    const float var = ss / (float)cols;
+    return 1.0f / __builtin_sqrtf(var + eps);
+}
+template <int DT>
+__device__ __forceinline__ float rms_h(float x, float w, float rs) {
+    const float xn = Elem<DT>::to_f32(Elem<DT>::from_f32(x * rs));
+    return w * xn;       // the caller rounds to the storage dtype
+}
+
+template <int DT, int VPT, bool WRITE_H>
+__global__ __launch_bounds__(256) void rmsnorm_quant_vec(const uint8_t* __restrict__ x, int64_t ldx_bytes, const uint8_t* __restrict__ wgt,
+                                                         float eps, int cols, int nvec, int8_t* __restrict__ q, int64_t ldq,
+                                                         float* __restrict__ scale, uint8_t* __restrict__ h_out, int64_t ldh_bytes) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const int t = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const uint8_t* xr = x + row * ldx_bytes;
+    v4u xv[VPT], wv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = i * 256 + t;
+        const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
+        xv[i] = *reinterpret_cast<const v4u*>(xr + off);
+        wv[i] = *reinterpret_cast<const v4u*>(wgt + off);
+    }
+    float acc = 0.0f;                       // N2: this lane's vectors in increasing v, elements in order
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        if (i * 256 + t >= nvec) xv[i] = v4u{0u, 0u, 0u, 0u};      // past the row: fma(0, 0, acc) = acc
+        float f[EPV];
+        Unpack<DT, EPV>::run(xv[i], f);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc = __builtin_fmaf(f[j], f[j], acc);
+    }
+    const float rs = rms_rs(rms_block_sum(acc), cols, eps);        // N3, N4
+    v4u hv[VPT];
+    uint32_t ab = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        float f[EPV], wf[EPV];
+        Unpack<DT, EPV>::run(xv[i], f);
+        Unpack<DT, EPV>::run(wv[i], wf);
+        if constexpr (DT == PQ_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[i][j] = __builtin_bit_cast(uint32_t, rms_h<DT>(f[j], wf[j], rs));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = Elem<DT>::from_f32(rms_h<DT>(f[2 * j], wf[2 * j], rs));
+                const uint32_t hi = Elem<DT>::from_f32(rms_h<DT>(f[2 * j + 1], wf[2 * j + 1], rs));
+                hv[i][j] = lo | (hi << 16);
+            }
+        }
+        ab = vec_amax_bits<DT>(hv[i], ab);
+        if constexpr (WRITE_H) {
+            const int idx = i * 256 + t;
+            if (idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+        }
+    }
+    reduce_and_encode<DT, VPT, 256>(hv, ab, t, nvec, true, row, q, ldq, scale);
+}
+
+// generic path (ragged widths, unaligned pointers): the same lane layout walked element by element.
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_quant_generic(const void* __restrict__ x, int64_t ldx, const void* __restrict__ wgt, float eps,
+                                                             int64_t cols, int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale,
+                                                             void* __restrict__ h_out, int64_t ldh) {
+    using S = typename Elem<DT>::store_t;
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const int64_t row = blockIdx.x;
+    const S* xr = reinterpret_cast<const S*>(x) + row * ldx;
+    const S* wr = reinterpret_cast<const S*>(wgt);
+    const int64_t nvec = (cols + EPV - 1) / EPV;
+    float acc = 0.0f;
+    for (int64_t v = threadIdx.x; v < nvec; v += 256)
+        for (int e = 0; e < EPV && v * EPV + e < cols; ++e) {
+            const float f = Elem<DT>::to_f32(xr[v * EPV + e]);
+            acc = __builtin_fmaf(f, f, acc);
+        }
+    const float rs = rms_rs(rms_block_sum(acc), (int)cols, eps);
+    auto h_at = [&](int64_t c) -> S { return Elem<DT>::from_f32(rms_h<DT>(Elem<DT>::to_f32(xr[c]), Elem<DT>::to_f32(wr[c]), rs)); };
     float amax = 0.0f;
     for (int64_t c = threadIdx.x; c < cols; c += 256) {
         const S h = h_at(c);
@@ -342,7 +465,7 @@ template <int DT>
 void silu_mul_quant_dispatch(const void* g, int64_t ldg, const void* u, int64_t ldu, int64_t rows, int64_t cols, int8_t* q,
                              int64_t ldq, float* scale, void* h_out, int64_t ldh, hipStream_t st) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
-    const bool vec_ok = (cols % EPV == 0) && (ldg % EPV == 0) && (ldu % EPV == 0) && aligned_to(g, 16) && aligned_to(u, 16) &&
+    const bool vec_ok = cols > 0 && (cols % EPV == 0) && (ldg % EPV == 0) && (ldu % EPV == 0) && aligned_to(g, 16) && aligned_to(u, 16) &&
                         (ldq % EPV == 0) && aligned_to(q, EPV) && cols / EPV <= 256 * 16 &&
                         (!h_out || ((ldh % EPV == 0) && aligned_to(h_out, 16)));
     if (!vec_ok) {
@@ -365,6 +488,43 @@ void silu_mul_quant_dispatch(const void* g, int64_t ldg, const void* u, int64_t 
         else launch_silu_mul_vec<DT, 256, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
     }
 }
+
+template <int DT>
+void rmsnorm_quant_dispatch(const void* x, int64_t ldx, const void* wgt, float eps, int64_t rows, int64_t cols, int8_t* q, int64_t ldq,
+                            float* scale, void* h_out, int64_t ldh, hipStream_t st) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned_to(x, 16) && aligned_to(wgt, 16) && (ldq % EPV == 0) &&
+                        aligned_to(q, EPV) && cols / EPV <= 256 * 16 && (!h_out || ((ldh % EPV == 0) && aligned_to(h_out, 16)));
+    const dim3 grid((unsigned)rows), block(256);
+    if (!vec_ok) {
+        rmsnorm_quant_generic<DT><<<grid, block, 0, st>>>(x, ldx, wgt, eps, cols, q, ldq, scale, h_out, ldh);
+        return;
+    }
+    const int nvec = (int)(cols / EPV);
+    int vpt = 1;
+    while (vpt * 256 < nvec) vpt <<= 1;
+    const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(wgt);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(h_out);
+    const int64_t kb = Elem<DT>::kBytes;
+#define PQ_RMS_LAUNCH(V)                                                                                                              \
+    do {                                                                                                                              \
+        if (h_out) rmsnorm_quant_vec<DT, V, true><<<grid, block, 0, st>>>(xb, ldx * kb, wb, eps, (int)cols, nvec, q, ldq, scale, hb, ldh * kb); \
+        else rmsnorm_quant_vec<DT, V, false><<<grid, block, 0, st>>>(xb, ldx * kb, wb, eps, (int)cols, nvec, q, ldq, scale, hb, 0);              \
+    } while (0)
+    switch (vpt) {
+        case 1: PQ_RMS_LAUNCH(1); break;
+        case 2: PQ_RMS_LAUNCH(2); break;
+        case 4: PQ_RMS_LAUNCH(4); break;
+        case 8: PQ_RMS_LAUNCH(8); break;
+        default: PQ_RMS_LAUNCH(16); break;
+    }
+#undef PQ_RMS_LAUNCH
+}
+
+template void rmsnorm_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+template void rmsnorm_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
+template void rmsnorm_quant_dispatch<PQ_F32>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 
 template void silu_mul_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template void silu_mul_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);

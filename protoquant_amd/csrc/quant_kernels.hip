@@ -327,7 +327,8 @@ template <int DT>
 void quant_rowwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t ldx, int8_t* q, int64_t ldq,
                             float* scale, hipStream_t st) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
-    const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) &&
+    // (cols == 0 goes to the generic kernel: it touches no element and writes scale = 1)
+    const bool vec_ok = cols > 0 && (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) &&
                         aligned(q, EPV) && cols / EPV <= 256 * 16;
     if (vec_ok) {
         const int nvec = (int)(cols / EPV);

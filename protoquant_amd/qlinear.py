@@ -182,9 +182,12 @@ class FusedQLinear(nn.Module):
     def from_linears(cls, *linears: nn.Linear) -> "FusedQLinear":
         return cls([qlinear.from_linear(l) for l in linears])
 
-    def forward(self, x: torch.Tensor):
-        xq = quantize(x, axis=-1)
-        y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, x.dtype)
+    def forward(self, x):
+        """x: a float tensor [..., K] or a per-token QTensor (e.g. from rmsnorm_quantize)."""
+        xq = x if isinstance(x, QTensor) else quantize(x, axis=-1)
+        if xq.axis != 1 or xq.shape[-1] != self.in_features:
+            raise ValueError("FusedQLinear: input must be [..., in_features], quantised per token if a QTensor")
+        y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, xq.orig_dtype)
         y = y.reshape(*x.shape[:-1], self.out_features)
         return torch.split(y, self.splits, dim=-1)
 

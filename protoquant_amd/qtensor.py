@@ -104,6 +104,30 @@ def silu_mul_quantize(g: torch.Tensor, u: torch.Tensor, return_h: bool = False):
     return (qt, h.reshape(g.shape)) if return_h else qt
 
 
+def rmsnorm_quantize(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, return_h: bool = False):
+    """quantize(weight * (x.float() * rsqrt(mean(x.float()**2, -1) + eps)).to(x.dtype), axis=-1) in ONE pass (kernel K1
+    fused into RMSNorm): the normalised activation feeding q/k/v or gate/up is reduced, scaled and encoded in registers.
+    Numerics: QSPEC N1-N6 (pinned reduction order) then Q1-Q6.  return_h=True also returns the normalised activation."""
+    L.require_gpu(x, "rmsnorm_quantize(x)")
+    L.require_gpu(weight, "rmsnorm_quantize(weight)")
+    if x.dim() < 1 or weight.dim() != 1 or weight.shape[0] != x.shape[-1] or weight.dtype != x.dtype or weight.device != x.device:
+        raise ValueError(f"rmsnorm_quantize: x {tuple(x.shape)} {x.dtype} needs a weight of shape ({x.shape[-1] if x.dim() else '?'},) "
+                         f"and the same dtype/device, got {tuple(weight.shape)} {weight.dtype}")
+    code = L.dtype_code(x.dtype)
+    x2 = _rows_view(x)
+    w = weight.contiguous()
+    rows, cols = x2.shape
+    q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    h = torch.empty((rows, cols), dtype=x.dtype, device=x.device) if return_h else None
+    with torch.cuda.device(x.device):
+        L.check(L.lib().pq_rmsnorm_quant_rowwise(x2.data_ptr(), L.ld(x2), w.data_ptr(), float(eps), code, rows, cols, q.data_ptr(),
+                                                 max(cols, 1), scale.data_ptr(), h.data_ptr() if return_h else None, max(cols, 1),
+                                                 L.stream_ptr(x)), "rmsnorm_quantize")
+    qt = QTensor(q.reshape(x.shape), scale, 1, x.dtype, x.shape)
+    return (qt, h.reshape(x.shape)) if return_h else qt
+
+
 def dequantize(q: QTensor, dtype: torch.dtype | None = None) -> torch.Tensor:
     """cast_rne(f32(int_data) * scale) along the kept axis -> `dtype` (default: the original dtype)."""
     dtype = dtype or q.orig_dtype

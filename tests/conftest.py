@@ -32,12 +32,25 @@ def golden(request):
     return load_golden(request.param)
 
 
-PRODUCER_GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "producer", "*.npz")))
+def _producer(kind):
+    return sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "producer", kind + "_*.npz")))
 
 
-@pytest.fixture(params=PRODUCER_GOLDEN, ids=[os.path.basename(p)[:-4] for p in PRODUCER_GOLDEN])
-def producer_golden(request):
-    z = np.load(request.param)
+def _load_npz(path):
+    z = np.load(path)
     d = {k: z[k] for k in z.files}
     d["code"] = int(d["code"])
     return d
+
+
+SILU_GOLDEN, RMS_GOLDEN = _producer("silu_mul"), _producer("rmsnorm")
+
+
+@pytest.fixture(params=SILU_GOLDEN, ids=[os.path.basename(p)[:-4] for p in SILU_GOLDEN])
+def producer_golden(request):
+    return _load_npz(request.param)
+
+
+@pytest.fixture(params=RMS_GOLDEN, ids=[os.path.basename(p)[:-4] for p in RMS_GOLDEN])
+def rms_golden(request):
+    return _load_npz(request.param)

@@ -565,6 +565,68 @@ def test_gated_mlp_matches_oracle_pipeline(pq):
     assert rel < 0.03, rel
 
 
+# ---------------------------------------------------------------- RMSNorm -> quantisation (QSPEC N1-N6)
+def test_golden_rmsnorm_quantize(pq, rms_golden):
+    g = rms_golden
+    code, eps = g["code"], float(g["eps"])
+    qt, h = pq.rmsnorm_quantize(to_gpu(g["x"], code), to_gpu(g["w"], code), eps, return_h=True)
+    same(qt.int_data, g["q"], "rms q"); same(qt.scale, g["scale"], "rms scale")
+    _same_h(h, g["h"], code, "rms h")
+    qt2 = pq.rmsnorm_quantize(to_gpu(g["x"], code), to_gpu(g["w"], code), eps)
+    same(qt2.int_data, g["q"], "rms q (no h)"); same(qt2.scale, g["scale"], "rms scale (no h)")
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (7, 13), (33, 1000), (64, 4096), (5, 11008), (3, 28672), (2, 40000), (300, 512),
+                                       (1, 8), (130, 2048), (4, 0), (17, 8192), (2, 65536 + 8)])
+def test_rmsnorm_quant_vs_oracle(pq, code, rows, cols):
+    """Vector path (up to 4096 16-byte vectors per row) and generic path (ragged / wider), rows with very different
+    magnitudes, contiguous and strided x."""
+    rng = np.random.default_rng(rows * 977 + cols + code)
+    x = Q.from_f32((rng.standard_normal((rows, cols)) * rng.uniform(0.01, 50.0, (rows, 1))).astype(np.float32), code)
+    w = Q.from_f32((1.0 + 0.3 * rng.standard_normal(cols)).astype(np.float32), code)
+    want_q, want_s, want_h, _ = C.rmsnorm_quant_rowwise(x, w, 1e-5, code)
+    qt, h = pq.rmsnorm_quantize(to_gpu(x, code), to_gpu(w, code), 1e-5, return_h=True)
+    same(qt.int_data, want_q, "q"); same(qt.scale, want_s, "scale"); _same_h(h, want_h, code, "h")
+    if cols:
+        wide = torch.zeros((rows, cols + 16), dtype=TD[code], device="cuda")
+        wide[:, :cols] = to_gpu(x, code)
+        qt = pq.rmsnorm_quantize(wide[:, :cols], to_gpu(w, code), 1e-5)
+        same(qt.int_data, want_q, "q (strided)"); same(qt.scale, want_s, "scale (strided)")
+
+
+def test_rmsnorm_many_rows_pins_sqrt_and_division(pq):
+    """65536 rows of 8 values with variances spread over 60 binades: every row exercises the IEEE 1/sqrt(var + eps)."""
+    rng = np.random.default_rng(8)
+    rows, cols = 65536, 8
+    x = (rng.standard_normal((rows, cols)) * np.exp2(rng.uniform(-30, 30, (rows, 1)))).astype(np.float32)
+    w = np.ones(cols, np.float32)
+    want_q, want_s, want_h, _ = C.rmsnorm_quant_rowwise(x, w, 1e-12, 2)
+    qt, h = pq.rmsnorm_quantize(to_gpu(x, 2), to_gpu(w, 2), 1e-12, return_h=True)
+    same(qt.int_data, want_q, "q"); same(qt.scale, want_s, "scale"); _same_h(h, want_h, 2, "h")
+
+
+def test_rmsnorm_quantize_feeds_fused_qkv(pq):
+    """rmsnorm_quantize -> FusedQLinear(q, k, v) on the QTensor == the oracle pipeline, bit for bit."""
+    M, H = 96, 512
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(M, H, generator=gen) * 3).to(torch.bfloat16)
+    wn = (1 + 0.1 * torch.randn(H, generator=gen)).to(torch.bfloat16)
+    lins = [torch.nn.Linear(H, n, bias=False, dtype=torch.bfloat16) for n in (512, 128, 128)]
+    with torch.no_grad():
+        for l in lins:
+            l.weight.copy_((torch.randn(l.weight.shape, generator=gen) * 0.04).to(torch.bfloat16))
+    import copy
+    fused = pq.FusedQLinear.from_linears(*(copy.deepcopy(l).cuda() for l in lins))
+    outs = fused(pq.rmsnorm_quantize(x.cuda(), wn.cuda(), 1e-5))
+    hq, hs, _, _ = C.rmsnorm_quant_rowwise(bits(x), bits(wn), 1e-5, 0)
+    for l, o in zip(lins, outs):
+        wq, ws = C.quant_rowwise(bits(l.weight), 0)
+        same(o.contiguous(), C.qlinear_s8(hq, hs, wq, ws, None, 0), "fused qkv on rmsnorm_quantize")
+    with pytest.raises(ValueError):
+        pq.rmsnorm_quantize(x.cuda(), wn.cuda()[:100])
+
+
 def test_randomized_shape_sweep(pq):
     """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
     arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""

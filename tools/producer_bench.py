@@ -41,5 +41,24 @@ def main():
               f"unfused: torch silu*mul {t_e:7.1f} us + K1 {t_q:6.1f} us = {t_e + t_q:7.1f} us   speed-up {(t_e + t_q) / t_f:4.2f}x")
 
 
+def rms():
+    for M, H in ((4096, 4096), (4096, 8192), (16384, 4096)):
+        x = torch.randn(M, H, device="cuda").to(torch.bfloat16)
+        w = torch.ones(H, device="cuda", dtype=torch.bfloat16)
+
+        def eager():
+            xf = x.float()
+            return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16)
+
+        t_f = timeit(lambda: pq.rmsnorm_quantize(x, w, 1e-5))
+        t_e = timeit(eager)
+        h = eager()
+        t_q = timeit(lambda: pq.quantize(h))
+        alg = M * H * 3 + 4 * M
+        print(f"rmsnorm {M:5d} x {H:5d} bf16  fused {t_f:7.1f} us ({alg / t_f / 1e6:5.2f} TB/s of algorithmic bytes)   unfused: torch eager "
+              f"chain {t_e:7.1f} us + K1 {t_q:6.1f} us   speed-up {(t_e + t_q) / t_f:4.2f}x")
+
+
 if __name__ == "__main__":
     main()
+    rms()
