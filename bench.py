@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--norms", action="store_true", help="llama8b workload: also run the two RMSNorms of every layer, fused into the activation quantisation (rmsnorm_quantize)")
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
@@ -168,12 +169,15 @@ def run_llama8b(args):
     head = mkq(V, H)
     x0 = torch.randn(M, H, device=dev).to(torch.bfloat16)
 
+    norm_w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+
     def fwd():
         x = x0
         for qkv, o, gu, down in layers:
-            a = qkv(x)[:, :H].contiguous()
+            # --norms: the layer's two RMSNorms, fused into the quantisation of the qkv and gate/up inputs (K1n replaces K1)
+            a = qkv(pq.rmsnorm_quantize(x, norm_w, 1e-5) if args.norms else x)[:, :H].contiguous()
             x = o(a)
-            g_u = gu(x)
+            g_u = gu(pq.rmsnorm_quantize(x, norm_w, 1e-5) if args.norms else x)
             if args.unfused_silu:
                 x = down(torch.nn.functional.silu(g_u[:, :I]) * g_u[:, I:])
             else:
@@ -193,6 +197,7 @@ def run_llama8b(args):
                       "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": "Llama-3-8B every linear as qlinear (qkv and gate/up fused), bs 1 seq 4096, linears + quant passes only (BASELINE configs[3])",
+                                 "rmsnorm": "fused into K1 (pq_rmsnorm_quant_rowwise)" if args.norms else "not run",
                                  "launch": "eager", "int8_ops_per_step": ops},
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,

@@ -353,6 +353,27 @@ __device__ __forceinline__ float rms_h(float x, float w, float rs) {
     return w * xn;       // the caller rounds to the storage dtype
 }
 
+template <int DT>
+__device__ __forceinline__ v4u rms_h_vec(const v4u& xv, const v4u& wv, float rs) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    float f[EPV], wf[EPV];
+    Unpack<DT, EPV>::run(xv, f);
+    Unpack<DT, EPV>::run(wv, wf);
+    v4u out;
+    if constexpr (DT == PQ_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = __builtin_bit_cast(uint32_t, rms_h<DT>(f[j], wf[j], rs));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = Elem<DT>::from_f32(rms_h<DT>(f[2 * j], wf[2 * j], rs));
+            const uint32_t hi = Elem<DT>::from_f32(rms_h<DT>(f[2 * j + 1], wf[2 * j + 1], rs));
+            out[j] = lo | (hi << 16);
+        }
+    }
+    return out;
+}
+
 template <int DT, int VPT, bool WRITE_H>
 __global__ __launch_bounds__(256) void rmsnorm_quant_vec(const uint8_t* __restrict__ x, int64_t ldx_bytes, const uint8_t* __restrict__ wgt,
                                                          float eps, int cols, int nvec, int8_t* __restrict__ q, int64_t ldq,
@@ -383,20 +404,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_vec(const uint8_t* __restri
     uint32_t ab = 0;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        float f[EPV], wf[EPV];
-        Unpack<DT, EPV>::run(xv[i], f);
-        Unpack<DT, EPV>::run(wv[i], wf);
-        if constexpr (DT == PQ_F32) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hv[i][j] = __builtin_bit_cast(uint32_t, rms_h<DT>(f[j], wf[j], rs));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo = Elem<DT>::from_f32(rms_h<DT>(f[2 * j], wf[2 * j], rs));
-                const uint32_t hi = Elem<DT>::from_f32(rms_h<DT>(f[2 * j + 1], wf[2 * j + 1], rs));
-                hv[i][j] = lo | (hi << 16);
-            }
-        }
+        hv[i] = rms_h_vec<DT>(xv[i], wv[i], rs);
         ab = vec_amax_bits<DT>(hv[i], ab);
         if constexpr (WRITE_H) {
             const int idx = i * 256 + t;
@@ -404,6 +412,58 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_vec(const uint8_t* __restri
         }
     }
     reduce_and_encode<DT, VPT, 256>(hv, ab, t, nvec, true, row, q, ldq, scale);
+}
+
+// Short rows (at most 512 vectors, e.g. a 4096-wide bf16 hidden state): one WAVE per row, four rows per block and no block
+// barrier, like K1.  The wave plays all four 64-lane groups of the specification: physical lane l holds virtual lanes
+// l, l+64, l+128, l+192 (vector v = i*64 + l belongs to virtual lane v mod 256 = (i mod 4)*64 + l), keeps one accumulator
+// per group, runs the xor butterfly on each and adds the four sums left to right — the same float operations in the same
+// order as the 256-thread layout, so the same bits.
+template <int DT, int VPT, bool WRITE_H>
+__global__ __launch_bounds__(256) void rmsnorm_quant_wave(const uint8_t* __restrict__ x, int64_t ldx_bytes, const uint8_t* __restrict__ wgt,
+                                                          float eps, int cols, int nvec, int64_t rows, int8_t* __restrict__ q, int64_t ldq,
+                                                          float* __restrict__ scale, uint8_t* __restrict__ h_out, int64_t ldh_bytes) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const int t = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool active = row < rows;
+    row = active ? row : rows - 1;
+    const uint8_t* xr = x + row * ldx_bytes;
+    v4u xv[VPT], wv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = i * 64 + t;
+        const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
+        xv[i] = *reinterpret_cast<const v4u*>(xr + off);
+        wv[i] = *reinterpret_cast<const v4u*>(wgt + off);
+    }
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        if (i * 64 + t >= nvec) xv[i] = v4u{0u, 0u, 0u, 0u};
+        float f[EPV];
+        Unpack<DT, EPV>::run(xv[i], f);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[i & 3] = __builtin_fmaf(f[j], f[j], acc[i & 3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) acc[gi] = acc[gi] + __shfl_xor(acc[gi], off, 64);
+    }
+    const float rs = rms_rs(((acc[0] + acc[1]) + acc[2]) + acc[3], cols, eps);
+    v4u hv[VPT];
+    uint32_t ab = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        hv[i] = rms_h_vec<DT>(xv[i], wv[i], rs);
+        ab = vec_amax_bits<DT>(hv[i], ab);
+        if constexpr (WRITE_H) {
+            const int idx = i * 64 + t;
+            if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+        }
+    }
+    reduce_and_encode<DT, VPT, 64>(hv, ab, t, nvec, active, row, q, ldq, scale);
 }
 
 // generic path (ragged widths, unaligned pointers): the same lane layout walked element by element.
@@ -501,12 +561,26 @@ void rmsnorm_quant_dispatch(const void* x, int64_t ldx, const void* wgt, float e
         return;
     }
     const int nvec = (int)(cols / EPV);
-    int vpt = 1;
-    while (vpt * 256 < nvec) vpt <<= 1;
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(wgt);
     uint8_t* hb = reinterpret_cast<uint8_t*>(h_out);
     const int64_t kb = Elem<DT>::kBytes;
+    if (nvec <= 64 * 8) {                 // one wave per row (rmsnorm_quant_wave): VPT in {4, 8} keeps i & 3 meaningful
+        const dim3 wgrid((unsigned)((rows + 3) / 4));
+#define PQ_RMSW_LAUNCH(V)                                                                                                                 \
+    do {                                                                                                                              \
+        if (h_out) rmsnorm_quant_wave<DT, V, true><<<wgrid, block, 0, st>>>(xb, ldx * kb, wb, eps, (int)cols, nvec, rows, q, ldq, scale, hb, ldh * kb); \
+        else rmsnorm_quant_wave<DT, V, false><<<wgrid, block, 0, st>>>(xb, ldx * kb, wb, eps, (int)cols, nvec, rows, q, ldq, scale, hb, 0);              \
+    } while (0)
+        if (nvec <= 64) PQ_RMSW_LAUNCH(1);
+        else if (nvec <= 128) PQ_RMSW_LAUNCH(2);
+        else if (nvec <= 256) PQ_RMSW_LAUNCH(4);
+        else PQ_RMSW_LAUNCH(8);
+#undef PQ_RMSW_LAUNCH
+        return;
+    }
+    int vpt = 1;
+    while (vpt * 256 < nvec) vpt <<= 1;
 #define PQ_RMS_LAUNCH(V)                                                                                                              \
     do {                                                                                                                              \
         if (h_out) rmsnorm_quant_vec<DT, V, true><<<grid, block, 0, st>>>(xb, ldx * kb, wb, eps, (int)cols, nvec, q, ldq, scale, hb, ldh * kb); \
