@@ -38,6 +38,15 @@ int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void*
 int32_t pq_unstack_cols(const void* stacked, void* y_full, int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype,
                         void* stream);
 
+/* Row-sharded (K-split) qlinear, the Megatron pairing of a column-sharded producer: every rank holds
+ * partial[nranks * m_shard, N] in f32 — its K-slice's contribution to the whole output — and receives the SUM over ranks of
+ * row block `rank`: y_rows[m_shard, N], cast (RNE) to out_dtype.  One ncclReduceScatter (f32, sum) — row blocks are
+ * contiguous, so there is no layout pass — plus a cast kernel when out_dtype is 16-bit (the f32 sum lands in `workspace`).
+ * Summation order across ranks is RCCL's: exact for nranks <= 2, within (nranks - 1) f32 ulps otherwise. */
+size_t pq_reduce_scatter_rows_workspace_bytes(int32_t nranks, int64_t m_shard, int64_t N, int32_t out_dtype);
+int32_t pq_reduce_scatter_rows(void* comm, int32_t nranks, const float* partial, void* y_rows, int64_t m_shard, int64_t N,
+                               int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,9 @@
 libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eager fallback."""
 from .qtensor import QTensor, quantize, dequantize, silu_mul_quantize, rmsnorm_quantize
 from .qlinear import qlinear, qlinear_s8, qlinear_dyn, int_mm, swap_linears, FusedQLinear, GatedMLP
-from .sharded import ColumnShardedQLinear, RcclColumnGather, gather_columns, shard_bounds
+from .sharded import (ColumnShardedQLinear, RcclColumnGather, RcclRowReduceScatter, RowShardedQLinear, ShardedGatedMLP,
+                      gather_columns, reduce_rows, shard_bounds)
 
 __all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "qlinear_dyn", "int_mm", "swap_linears", "FusedQLinear", "GatedMLP", "silu_mul_quantize", "rmsnorm_quantize",
-           "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds"]
+           "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds", "RowShardedQLinear", "ShardedGatedMLP",
+           "RcclRowReduceScatter", "reduce_rows"]

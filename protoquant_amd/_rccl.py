@@ -1,4 +1,5 @@
-"""ctypes binding of libpq_rccl.so (include/pq_rccl.h): RCCL communicator bootstrap + the column all-gather.
+"""ctypes binding of libpq_rccl.so (include/pq_rccl.h): RCCL communicator bootstrap, the column all-gather and the
+row reduce-scatter.
 No fallback: a missing library raises."""
 from __future__ import annotations
 
@@ -13,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpq_rccl.so")
 UNIQUE_ID_BYTES = 128
 EXPORTS = ("pq_rccl_last_error", "pq_comm_unique_id", "pq_comm_init_rank", "pq_comm_destroy",
-           "pq_allgather_cols_workspace_bytes", "pq_allgather_cols", "pq_unstack_cols")
+           "pq_allgather_cols_workspace_bytes", "pq_allgather_cols", "pq_unstack_cols",
+           "pq_reduce_scatter_rows_workspace_bytes", "pq_reduce_scatter_rows")
 _lib = None
 i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 
@@ -38,6 +40,10 @@ def lib() -> ctypes.CDLL:
     L.pq_allgather_cols.argtypes = [vp, i32, vp, vp, i64, i64, i32, vp, sz, vp]
     L.pq_unstack_cols.restype = i32
     L.pq_unstack_cols.argtypes = [vp, vp, i32, i64, i64, i32, vp]
+    L.pq_reduce_scatter_rows_workspace_bytes.restype = sz
+    L.pq_reduce_scatter_rows_workspace_bytes.argtypes = [i32, i64, i64, i32]
+    L.pq_reduce_scatter_rows.restype = i32
+    L.pq_reduce_scatter_rows.argtypes = [vp, i32, vp, vp, i64, i64, i32, vp, sz, vp]
     _lib = L
     return L
 

@@ -1,4 +1,5 @@
-// pq_rccl.hip — libpq_rccl.so (include/pq_rccl.h): RCCL all-gather of column shards + layout fix.
+// pq_rccl.hip — libpq_rccl.so (include/pq_rccl.h): RCCL all-gather of column shards + layout fix, and the
+// reduce-scatter of row-sharded partial outputs + cast.
 // Kept apart from libpq_hip.so so the compute library has no communication dependency.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -41,6 +42,16 @@ int32_t launch_unstack(const void* stacked, void* y_full, int32_t nranks, int64_
     else unstack_kernel<unsigned short><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(reinterpret_cast<const unsigned short*>(stacked), reinterpret_cast<unsigned short*>(y_full), nranks, M, row_bytes / 2);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(3, "unstack launch: %s", hipGetErrorString(e));
+}
+// f32 -> bf16 / fp16 / f32 (RNE) of a contiguous block; the cast after the f32 sum of row-sharded partial outputs
+template <int DT>
+__global__ __launch_bounds__(256) void cast_from_f32(const float* __restrict__ in, void* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = in[i];
+        if constexpr (DT == 0) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+        else if constexpr (DT == 1) reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
+        else reinterpret_cast<float*>(out)[i] = v;
+    }
 }
 }  // namespace
 
@@ -97,6 +108,34 @@ int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void*
     const ncclResult_t r = ncclAllGather(y_shard, workspace, need / (size_t)nranks, ncclInt8, static_cast<ncclComm_t>(comm), st);
     if (r != ncclSuccess) return fail(6, "ncclAllGather: %s", ncclGetErrorString(r));
     return launch_unstack(workspace, y_full, nranks, M, n_shard, dtype, st);
+}
+
+size_t pq_reduce_scatter_rows_workspace_bytes(int32_t nranks, int64_t m_shard, int64_t N, int32_t out_dtype) {
+    if (nranks < 1 || m_shard < 0 || N < 0 || out_dtype < 0 || out_dtype > 2) return 0;
+    return out_dtype == 2 ? 0 : (size_t)m_shard * (size_t)N * sizeof(float);
+}
+
+int32_t pq_reduce_scatter_rows(void* comm, int32_t nranks, const float* partial, void* y_rows, int64_t m_shard, int64_t N,
+                               int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!comm || nranks < 1 || m_shard < 0 || N < 0 || out_dtype < 0 || out_dtype > 2) return fail(1, "pq_reduce_scatter_rows: bad arguments");
+    const size_t count = (size_t)m_shard * (size_t)N;
+    if (count == 0) return 0;
+    if (!partial || !y_rows) return fail(1, "pq_reduce_scatter_rows: null buffer");
+    const size_t need = pq_reduce_scatter_rows_workspace_bytes(nranks, m_shard, N, out_dtype);
+    if (need && (!workspace || workspace_bytes < need)) return fail(5, "pq_reduce_scatter_rows: workspace %zu < %zu bytes", workspace ? workspace_bytes : (size_t)0, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* sum = out_dtype == 2 ? static_cast<float*>(y_rows) : static_cast<float*>(workspace);
+    const ncclResult_t r = ncclReduceScatter(partial, sum, count, ncclFloat, ncclSum, static_cast<ncclComm_t>(comm), st);
+    if (r != ncclSuccess) return fail(6, "ncclReduceScatter: %s", ncclGetErrorString(r));
+    if (out_dtype != 2) {
+        int64_t blocks = ((int64_t)count + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (out_dtype == 0) cast_from_f32<0><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(sum, y_rows, (int64_t)count);
+        else cast_from_f32<1><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(sum, y_rows, (int64_t)count);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(3, "cast launch: %s", hipGetErrorString(e));
+    }
+    return 0;
 }
 
 }  // extern "C"

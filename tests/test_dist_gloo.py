@@ -63,3 +63,46 @@ def test_shard_bounds_cover_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(8, 2, 2)
+
+
+def _rr_worker(rank, world, port, M, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from protoquant_amd.sharded import reduce_rows, shard_bounds
+        g = torch.Generator().manual_seed(100 + M + N)
+        parts = [torch.randn(M, N, generator=g) * (r + 1) for r in range(world)]     # every rank can rebuild all partials
+        total = parts[0] + parts[1]
+        lo, hi = shard_bounds(M, world, rank)
+        ok = True
+        for dt in (torch.float32, torch.bfloat16):
+            mine = reduce_rows(parts[rank].clone(), dt, scatter=True)
+            ok = ok and mine.shape == (hi - lo, N) and torch.equal(mine, total[lo:hi].to(dt))
+            full = reduce_rows(parts[rank].clone(), dt, scatter=False)
+            ok = ok and full.shape == (M, N) and torch.equal(full, total.to(dt))
+        try:
+            reduce_rows(parts[rank].to(torch.bfloat16), torch.bfloat16)
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,N", [(8, 16), (7, 5), (1, 3), (256, 64)])
+def test_reduce_rows_world2(M, N):
+    """Row-sharded qlinear's one collective: f32 partial outputs summed over ranks, scattered by balanced row blocks
+    (ragged M padded for the collective) or all-reduced; cast once."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rr_worker, args=(r, world, port, M, N, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -379,6 +379,109 @@ def test_native_rccl_gather(pq):
             dist.destroy_process_group()
 
 
+def _oracle_row_sharded(x_bits, lin, world, code=0):
+    """QSPEC restatement of the row-sharded linear: full-row weight scales, per-slice activation scales, f32 partials
+    (bias on rank 0) summed in rank order, one cast."""
+    from protoquant_amd.sharded import shard_bounds
+    wq, ws = C.quant_rowwise(bits(lin.weight), code)
+    total = None
+    for r in range(world):
+        k0, k1 = shard_bounds(lin.in_features, world, r)
+        xq, xs = C.quant_rowwise(np.ascontiguousarray(x_bits[:, k0:k1]), code)
+        b = lin.bias.detach().float().cpu().numpy() if (lin.bias is not None and r == 0) else None
+        p = C.qlinear_s8(xq, xs, np.ascontiguousarray(wq[:, k0:k1]), ws, b, 2)
+        total = p if total is None else (total + p).astype(np.float32)
+    return Q.from_f32(total, code)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_row_sharded_partials_match_oracle(pq, world):
+    """Every rank's shard built offline (shard_of), partial() on one GPU, f32 sum in rank order, one cast == the oracle
+    restatement, bit for bit; world 1 == the plain qlinear."""
+    torch.manual_seed(11)
+    lin = torch.nn.Linear(640, 384, bias=True, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.mul_(3)
+    x = torch.randn(70, 640).to(torch.bfloat16)
+    from protoquant_amd.sharded import shard_bounds
+    import copy
+    lin_g = copy.deepcopy(lin).cuda()
+    total = None
+    for r in range(world):
+        k0, k1 = shard_bounds(640, world, r)
+        layer = pq.RowShardedQLinear.from_linear(lin_g, world=world, rank=r)
+        p = layer.partial(x[:, k0:k1].contiguous().cuda())
+        assert p.dtype == torch.float32 and p.shape == (70, 384)
+        total = p if total is None else total + p
+    y = total.to(torch.bfloat16)
+    same(y, _oracle_row_sharded(bits(x), lin, world), f"row-sharded world {world}")
+    if world == 1:
+        same(pq.qlinear.from_linear(lin_g)(x.cuda()), bits(y), "world 1 == qlinear")
+    ref = lin.float()(x.float())
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) < 0.02
+
+
+def test_sharded_gated_mlp_partials(pq):
+    """ShardedGatedMLP shards built offline for 2 ranks: sum of the ranks' down partials == the oracle pipeline (per-rank
+    gate/up shard GEMMs, local silu*mul quantisation, K-split down), and close to the float MLP."""
+    M, H, I, world = 64, 256, 512, 2
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(M, H, generator=gen).to(torch.bfloat16)
+    lins = {n: torch.nn.Linear(i, o, bias=False, dtype=torch.bfloat16) for n, (o, i) in (("gate", (I, H)), ("up", (I, H)), ("down", (H, I)))}
+    with torch.no_grad():
+        for l in lins.values():
+            l.weight.copy_((torch.randn(l.weight.shape, generator=gen) * 0.05).to(torch.bfloat16))
+    import copy
+    from protoquant_amd.sharded import shard_bounds
+    g = {n: copy.deepcopy(l).cuda() for n, l in lins.items()}
+    xq, xs = C.quant_rowwise(bits(x), 0)
+    dq, ds = C.quant_rowwise(bits(lins["down"].weight), 0)
+    total, want = None, None
+    for r in range(world):
+        mlp = pq.ShardedGatedMLP.from_linears(g["gate"], g["up"], g["down"], world=world, rank=r)
+        gt, up = mlp.gate_up(x.cuda())
+        p = mlp.down.partial(pq.silu_mul_quantize(gt, up))
+        total = p if total is None else total + p
+        lo, hi = shard_bounds(I, world, r)
+        wg = C.quant_rowwise(bits(lins["gate"].weight[lo:hi]), 0); wu = C.quant_rowwise(bits(lins["up"].weight[lo:hi]), 0)
+        hq, hs, _ = C.silu_mul_quant_rowwise(C.qlinear_s8(xq, xs, *wg, None, 0), C.qlinear_s8(xq, xs, *wu, None, 0), 0)
+        pw = C.qlinear_s8(hq, hs, np.ascontiguousarray(dq[:, lo:hi]), ds, None, 2)
+        want = pw if want is None else (want + pw).astype(np.float32)
+    same(total.to(torch.bfloat16), Q.from_f32(want, 0), "sharded gated MLP")
+    ref = lins["down"].float()(torch.nn.functional.silu(lins["gate"].float()(x.float())) * lins["up"].float()(x.float()))
+    assert float((total.cpu() - ref).norm() / ref.norm()) < 0.03
+
+
+def test_native_reduce_scatter_world1(pq):
+    """libpq_rccl.so pq_reduce_scatter_rows on a real 1-rank communicator: f32 partials -> bf16 / f32 rows, and
+    RowShardedQLinear(native=...) == plain qlinear."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        gather = pq.RcclColumnGather()
+        rs = pq.RcclRowReduceScatter(gather)
+        p = torch.randn(48, 200, device="cuda")
+        assert torch.equal(rs(p, torch.bfloat16), p.to(torch.bfloat16)) and torch.equal(rs(p, torch.float32), p)
+        assert torch.equal(rs(p, torch.float16), p.to(torch.float16))
+        torch.manual_seed(5)
+        lin = torch.nn.Linear(256, 384, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(64, 256, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        y1 = pq.RowShardedQLinear.from_linear(lin, native=rs)(x)
+        y2 = pq.RowShardedQLinear.from_linear(lin, scatter=False)(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(y0.view(torch.int16), y2.view(torch.int16))
+        gather.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_swap_linears_on_mlp(pq):
     """Llama-style MLP block (gate/up/down) with every nn.Linear swapped: each projection bit-exact vs the oracle."""
     torch.manual_seed(5)
