@@ -68,7 +68,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // TM: rows (m) of the output tile, 256 or 128.  TM = 128 halves the Q (activation) side — 16 rows per wave-half, one
 // 16x16 MFMA tile — for problems whose 256x256 grid would leave most CUs idle; it needs 48 KiB of DMA per
 // 1024 MFMA-cycles, so it runs ingest-bound (~3/4 of the 256-row tile's rate per CU).
-template <int OUT, int SHAPE, int ABL, int TM = 256>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
+// TN: columns (n) of the output tile, 256 or 128 (with TM = 128 only): a 128 x 128 tile for 1024-wide shards whose grid would
+// otherwise fill half the chip or need split-K.  It needs 32 KiB of DMA and 96 KiB of LDS fragment reads per 512
+// MFMA-cycles, so it runs LDS-read/ingest-bound — but with every CU busy and no slab traffic.
+template <int OUT, int SHAPE, int ABL, int TM = 256, int TN = 256>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -99,22 +102,26 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
     const int tin = t - band * GM * tiles_n;
     const int tm = band * GM + tin % gm, tn = tin / gm;
-    const int m0 = tm * TM, n0 = tn * FT;
+    const int m0 = tm * TM, n0 = tn * TN;
 
     static_assert(TM == 256 || (TM == 128 && SHAPE == 16), "TM = 128 needs the 16x16x64 shape");
+    static_assert(TN == 256 || (TN == 128 && TM == 128), "TN = 128 comes with TM = 128");
+    constexpr int PWH = TN / 4;           // P rows per wave per half-tile: 64 or 32
+    constexpr int PPW = TN / 128;         // DMA pieces per wave per P half-tile: 2 or 1 (a P half-tile is TN/2 rows)
     constexpr int QW = TM / 8;            // Q rows per wave per half-tile: 32 or 16
     constexpr int QPW = TM / 128;         // DMA pieces per wave per Q half-tile: 2 or 1 (a Q half-tile is TM/2 rows)
     // ---- staging source offsets: wave w issues pieces (w*2+jj), jj = 0,1, of every half-tile.
     // LDS row r = w*16 + jj*8 + (lane>>3) of the half-tile; physical chunk lane&7.
-    // P half h, LDS row r <-> n_local = (r>>6)*128 + h*64 + (r&63);  Q: m_local = (r/QW)*2QW + h*QW + (r%QW).
-    uint32_t offP[2][2], offQ[2][QPW];   // [half][jj] byte offset from the tile's first row, k = 0
+    // P half h, LDS row r <-> n_local = (r/PWH)*2PWH + h*PWH + (r%PWH);  Q: m_local = (r/QW)*2QW + h*QW + (r%QW).
+    uint32_t offP[2][PPW], offQ[2][QPW];   // [half][jj] byte offset from the tile's first row, k = 0
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int r = w * 16 + jj * 8 + (lane >> 3);
-            const int src_chunk = (lane & 7) ^ (jj * 4 + (lane >> 4));
-            int nl = (r >> 6) * 128 + h * 64 + (r & 63);
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int piece = w * PPW + jj;               // LDS rows piece*8 .. +7 of the P half-tile
+            const int r = piece * 8 + (lane >> 3);
+            const int src_chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+            int nl = (r / PWH) * (2 * PWH) + h * PWH + (r % PWH);
             nl = (n0 + nl < N) ? nl : (N - 1 - n0);       // clamp: rows past the edge re-read a valid row
             offP[h][jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
         }
@@ -130,11 +137,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     }
     const int8_t* gP = W + (int64_t)n0 * ldw + (int64_t)kslice * Ks;   // uniform; advanced by FBK per staged K-tile
     const int8_t* gQ = X + (int64_t)m0 * ldx + (int64_t)kslice * Ks;
-    const int piece_off = w * 2048;             // pieces w*2 and w*2+1 of a half-tile
+    const int piece_off = w * PPW * 1024;       // this wave's PPW pieces of a P half-tile
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;   // LDS byte address of the array
 
     // ---- fragment read addresses (lane part)
-    constexpr int NPI = (SHAPE == 16) ? 4 : 2;     // P tiles per half (64 rows)
+    constexpr int NPI = (SHAPE == 16) ? PWH / 16 : 2;  // P tiles per wave-half (PWH rows)
     constexpr int NQJ = (SHAPE == 16) ? QW / 16 : 1;   // Q tiles per wave-half (QW rows)
     constexpr int NKS = (SHAPE == 16) ? 2 : 4;     // MFMA k-steps per 128-byte row
     constexpr int NACC = (SHAPE == 16) ? 4 : 16;   // accumulator registers per tile
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int c = ks * (8 / NKS) + fchunk;
-        lP[ks] = (uint32_t)((wp * 64 + frow) * 128 + ((c ^ fkey) * 16));
+        lP[ks] = (uint32_t)((wp * PWH + frow) * 128 + ((c ^ fkey) * 16));
         lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * HALF_BYTES;
     }
 
@@ -175,14 +182,14 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     }
 
     // ---- issue items.  Everything below is hand-interleaved: ONE item in the shadow of each MFMA.
-    // DMA piece g of a K-tile, in need order P0a P0b | Q0 (QPW pieces) | Q1 (QPW pieces) | P1a P1b
-    constexpr int NDMA = 4 + 2 * QPW;
+    // DMA piece g of a K-tile, in need order P0 (PPW pieces) | Q0 (QPW pieces) | Q1 (QPW pieces) | P1 (PPW pieces)
+    constexpr int NDMA = 2 * PPW + 2 * QPW;
     auto dma_item = [&](int buf, auto gc) {
         constexpr int g = decltype(gc)::value;
         if constexpr (g < NDMA) {
-            constexpr bool isQ = (g >= 2 && g < 2 + 2 * QPW);
-            constexpr int h = isQ ? (g - 2) / QPW : (g >= 2 ? 1 : 0);
-            constexpr int jj = isQ ? (g - 2) % QPW : (g & 1);
+            constexpr bool isQ = (g >= PPW && g < PPW + 2 * QPW);
+            constexpr int h = isQ ? (g - PPW) / QPW : (g >= PPW ? 1 : 0);
+            constexpr int jj = isQ ? (g - PPW) % QPW : (g < PPW ? g : g - PPW - 2 * QPW);
             if (!no_dma) {
                 if constexpr (isQ) {
                     const uint32_t la = smem_base + buf * BUF_BYTES + 2 * HALF_BYTES + h * HALF_BYTES + (w * QPW + jj) * 1024;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     auto stage_tile = [&](int buf) {   // whole tile at once (prologue only)
         static_for<NDMA>([&](auto gc) { dma_item(buf, gc); });
     };
-    // fragment item it: P: i = it % NPI, ks = it / NPI (8 items); Q: j = it % NQJ, ks = it / NQJ (NQR items)
+    // fragment item it: P: i = it % NPI, ks = it / NPI (NPR items); Q: j = it % NQJ, ks = it / NQJ (NQR items)
     auto readP_item = [&](int bufoff, int h, v4i (&f)[NPI][NKS], auto ic) {
         constexpr int it = decltype(ic)::value, i = it % NPI, ks = it / NPI;
         if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * HALF_BYTES + i * SHAPE * 128);
@@ -207,12 +214,15 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         constexpr int it = decltype(ic)::value, j = it % NQJ, ks = it / NQJ;
         if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * HALF_BYTES + j * SHAPE * 128);
     };
-    auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<8>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
+    constexpr int NPR = NPI * NKS;               // P fragment reads per half: 8 or 4
+    auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<NPR>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
     constexpr int NQR = NQJ * NKS;               // Q fragment reads per half: 4 or 2
     auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) { static_for<NQR>([&](auto ic) { readQ_item(bufoff, h, f, ic); }); };
 
-    constexpr int NM = NKS * NPI * NQJ;          // MFMAs per quadrant: 16 or 8
-    constexpr int PPS = 8 / (NM / 2);            // P reads (or DMA pieces) per slot: 1 or 2
+    constexpr int NM = NKS * NPI * NQJ;          // MFMAs per quadrant: 16, 8 or 4
+    constexpr int PPS = NPR / (NM / 2);          // P reads per slot (half a quadrant's slots): 1 or 2
+    constexpr int DPS = (NDMA + NM / 2 - 1) / (NM / 2);   // DMA pieces per slot: 1 or 2
+    static_assert(PPS >= 1 && PPS * (NM / 2) == NPR && NQR <= NM, "slot plan");
     // One quadrant: MFMA idx, then slot(idx) in its shadow.  The first MFMA needs this quadrant's own
     // operands (all issued during the previous quadrant) -> hipcc's wait there is an exact lgkmcnt(0).
     auto mma = [&](acc_t (&c)[NPI][NQJ], v4i (&fp)[NPI][NKS], v4i (&fq)[NQJ][NKS], auto&& slot) {
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         mma(acc[1][0], fPb, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-            if constexpr (next2 && x >= NM / 2) static_for<PPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * PPS + decltype(pc)::value>{}); });
+            if constexpr (next2 && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
         });
         mma(acc[1][1], fPb, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         }
     }
     stage_tile(0);
-    if (NT > 1) { stage_tile(1); if constexpr (NDMA == 8) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0076); }   // vmcnt(NDMA) lgkmcnt(0)
+    if (NT > 1) { stage_tile(1); __builtin_amdgcn_s_waitcnt(0x0070 | NDMA); }   // vmcnt(NDMA) lgkmcnt(0)
     else { __builtin_amdgcn_s_waitcnt(0x0070); }                          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     readP(0, 0, fPa);
@@ -324,15 +334,18 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // first of 4 consecutive n (+8g for 32x32)
     constexpr int NG = (SHAPE == 16) ? 1 : 4;
     constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
-    const int wm0 = m0 + wq * WM, wn0 = n0 + wp * 128;                      // this wave's WM(m) x 128(n) block
+    constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
+    const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;                       // this wave's WM(m) x WN(n) block
 
     // staged path: whole block in range, 16-byte aligned rows
-    const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + 128 <= N) &&
+    const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
                         ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
     __builtin_amdgcn_s_barrier();     // every wave is done reading the K-loop buffers (uniform: all waves reach it)
     if (staged) {
         uint8_t* sw = smem + w * EPI_WAVE;
-        constexpr int NPASS = (OB == 2) ? 1 : 2;          // 256-byte rows: 128 n of 2 bytes, or 64 n of 4 bytes
+        constexpr int RB = (WN * OB < 256) ? WN * OB : 256;   // staged row: 256 bytes (128 n x 2 B, or 64 n x 4 B), 128 for 64 n x 2 B
+        constexpr int NPASS = WN * OB / RB;               // 2 only for the 128-n block of 4-byte outputs: one hP half per pass
+        constexpr int CPR = RB / 16;                      // 16-byte chunks per staged row (chunk c of row r at c ^ (r & (CPR-1)))
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -349,12 +362,12 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                         for (int i = 0; i < NPI; ++i)
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {
-                                const int nl = hP * 64 + i * SHAPE + drow4 + 8 * g;       // inside the wave block
+                                const int nl = hP * PWH + i * SHAPE + drow4 + 8 * g;      // inside the wave block
                                 const acc_t& c = acc[hP][hQ][i][j];
                                 v4f bs = {1.f, 1.f, 1.f, 1.f};
                                 float bf[4] = {0.f, 0.f, 0.f, 0.f};
                                 if constexpr (OUT != OUT_I32 && !const_scale) {
-                                    bs = *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * 128 + nl) * 4);
+                                    bs = *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * WN + nl) * 4);
                                     if (has_bias) {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                                 }
                                 const int ncol = (NPASS == 2) ? (nl - pass * 64) : nl;
                                 const int boff = ncol * OB;                              // byte offset inside the 256-B row
-                                uint8_t* d = sw + ml * EPI_ROW + ((((boff >> 4) ^ (ml & 15)) << 4) | (boff & 15));
+                                uint8_t* d = sw + ml * EPI_ROW + ((((boff >> 4) ^ (ml & (CPR - 1))) << 4) | (boff & 15));
                                 if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
                                 else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
                             }
@@ -388,9 +401,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             // wave-private region: only this wave's LDS writes must retire before its reads (no barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int it = 0; it < WM / 4; ++it) {
-                const int r = it * 4 + (lane >> 4), ch = lane & 15;
-                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ((ch ^ (r & 15)) << 4));
+            for (int it = 0; it < WM * CPR / 64; ++it) {
+                const int r = it * (64 / CPR) + lane / CPR, ch = lane % CPR;
+                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ((ch ^ (r & (CPR - 1))) << 4));
                 uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
                 if constexpr (no_store) { if (v[0] == 0x12345678u && v[3] == 0x0badf00du) *reinterpret_cast<v4u*>(dst) = v; }
                 else *reinterpret_cast<v4u*>(dst) = v;
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                 for (int i = 0; i < NPI; ++i)
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        const int n = wn0 + hP * 64 + i * SHAPE + drow4 + 8 * g;
+                        const int n = wn0 + hP * PWH + i * SHAPE + drow4 + 8 * g;
                         if (!mok || n >= N) continue;
                         const acc_t& c = acc[hP][hQ][i][j];
                         O* dst = y + (int64_t)m * epi.ldy + n;
@@ -459,13 +472,13 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
-template <int OUT, int SHAPE, int TM>
+template <int OUT, int SHAPE, int TM, int TN>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
                       int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
 #ifdef PQ_ABLATION_BUILD
-    if constexpr (OUT == PQ_BF16 && SHAPE == 16 && TM == 256) {
+    if constexpr (OUT == PQ_BF16 && SHAPE == 16 && TM == 256 && TN == 256) {
         switch (gemm_debug_flags()) {
 #define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
             PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(128) PQ_ABL(256) PQ_ABL(384) PQ_ABL(1024)
@@ -474,7 +487,7 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         }
     }
 #endif
-    gemm_s8_sp256<OUT, SHAPE, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+    gemm_s8_sp256<OUT, SHAPE, 0, TM, TN><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
 }
 
 // ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
@@ -533,11 +546,12 @@ template void launch_splitk_reduce<PQ_BF16>(const int32_t*, int, int64_t, int64_
 template void launch_splitk_reduce<PQ_FP16>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 template void launch_splitk_reduce<PQ_F32>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 
-#define PQ_INST(OUT, SHAPE, TM) \
-    template void launch_gemm_fast<OUT, SHAPE, TM>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-PQ_INST(PQ_BF16, 16, 256) PQ_INST(PQ_FP16, 16, 256) PQ_INST(PQ_F32, 16, 256) PQ_INST(OUT_I32, 16, 256)
-PQ_INST(PQ_BF16, 16, 128) PQ_INST(PQ_FP16, 16, 128) PQ_INST(PQ_F32, 16, 128) PQ_INST(OUT_I32, 16, 128)
-PQ_INST(PQ_BF16, 32, 256) PQ_INST(OUT_I32, 32, 256)
+#define PQ_INST(OUT, SHAPE, TM, TN) \
+    template void launch_gemm_fast<OUT, SHAPE, TM, TN>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+PQ_INST(PQ_BF16, 16, 256, 256) PQ_INST(PQ_FP16, 16, 256, 256) PQ_INST(PQ_F32, 16, 256, 256) PQ_INST(OUT_I32, 16, 256, 256)
+PQ_INST(PQ_BF16, 16, 128, 256) PQ_INST(PQ_FP16, 16, 128, 256) PQ_INST(PQ_F32, 16, 128, 256) PQ_INST(OUT_I32, 16, 128, 256)
+PQ_INST(PQ_BF16, 16, 128, 128) PQ_INST(PQ_FP16, 16, 128, 128) PQ_INST(PQ_F32, 16, 128, 128) PQ_INST(OUT_I32, 16, 128, 128)
+PQ_INST(PQ_BF16, 32, 256, 256) PQ_INST(OUT_I32, 32, 256, 256)
 #undef PQ_INST
 
 }  // namespace pq

@@ -37,7 +37,7 @@ def test_golden_quantize(pq, golden):
     same(pq.dequantize(qc), g["x_coldeq"], "x_coldeq")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128"])
 def test_golden_gemm_and_qlinear(pq, golden, variant, monkeypatch):
     g = golden
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -70,7 +70,7 @@ SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), 
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128"])
 def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
     """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -82,7 +82,7 @@ def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
     same(got, want, f"acc {M}x{N}x{K} {variant}")
 
 
-@pytest.mark.parametrize("variant", ["sp256_16", "sp256_32", "sp128_16", "generic"])
+@pytest.mark.parametrize("variant", ["sp256_16", "sp256_32", "sp128_16", "sp128x128", "generic"])
 def test_gemm_identity_asymmetric(pq, variant, monkeypatch):
     """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
     monkeypatch.setenv("PQ_FORCE_VARIANT", variant)
@@ -166,7 +166,7 @@ def test_quant_strided_and_unaligned(pq):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
                                               (512, 1024, 512, 0, False)])
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_32", "sp128_16"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_32", "sp128_16", "sp128x128"])
 def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, monkeypatch):
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M + N + K + code)
@@ -201,8 +201,8 @@ def test_qlinear_unaligned_scales_and_output(pq):
     same(out.contiguous(), want, "unaligned output")
 
 
-@pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 4096, 0, True), (512, 1024, 4096, 0, False), (130, 517, 4096, 2, True),
-                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False)])
+@pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 8192, 0, True), (512, 1024, 8192, 0, False), (130, 517, 8192, 2, True),
+                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (2304, 1024, 16384, 0, True)])
 def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
     == the single-pass kernel (PQ_NO_SPLITK)."""
@@ -212,7 +212,8 @@ def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
     xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
     bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
-    want = Q.epilogue((a.astype(np.int64) @ b.astype(np.int64).T).astype(np.int32), xs, ws, bv, code)
+    acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)      # exact: |acc| < 2^53 (BLAS, fast)
+    want = Q.epilogue(acc, xs, ws, bv, code)
     args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
             to_gpu(bv, code) if bias else None, TD[code])
     same(pq.qlinear_s8(*args), want, "split-K y")
@@ -246,7 +247,7 @@ def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
 def test_splitk_workspace_too_small_is_an_error(pq):
     from protoquant_amd import _lib
     L = _lib.lib()
-    M, N, K = 512, 1024, 4096
+    M, N, K = 512, 1024, 8192
     need = L.pq_qlinear_workspace_bytes(M, N, K)
     assert need > 0
     a = torch.zeros((M, K), dtype=torch.int8, device="cuda"); b = torch.zeros((N, K), dtype=torch.int8, device="cuda")
