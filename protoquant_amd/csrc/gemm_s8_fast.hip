@@ -546,6 +546,222 @@ template void launch_splitk_reduce<PQ_BF16>(const int32_t*, int, int64_t, int64_
 template void launch_splitk_reduce<PQ_FP16>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 template void launch_splitk_reduce<PQ_F32>(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 
+// ------------------------------------------------------------------------------------------------
+// gemm_s8_ring128 — 128 x 128 output tile, 4 waves (one per SIMD), wave tile 64(n) x 64(m): the variant for grids that fill
+// at most half the chip with the big tiles (1024-wide shards, M <= 512).  A tile this small needs 64 B/clk/CU of operand
+// ingest; at ~2000 cycles of L2 latency that is 128 KiB in flight per CU, so the design is a 4-deep ring of 32-KiB K-tiles
+// (three in flight while one is read) — the LDS capacity, not the MFMA rate, sets its ceiling (~3/4 of the MFMA rate).
+// Each wave keeps the fragments of the current K-tile in registers and reads ALL fragments of the next one (16 x
+// ds_read_b128) in the shadows of the current tile's 32 MFMAs; the DMA pieces of tile kt+4 follow in the next shadows.
+// One s_barrier per K-tile.  Same LDS image as the big kernel: [128 rows][128 B], 16-byte chunk c of row r at c ^ ((r>>1)&7).
+constexpr int R_TILE = 128, R_NBUF = 4, R_OPER = 128 * FBK /* 16 KiB */, R_BUF = 2 * R_OPER, R_LDS = R_NBUF * R_BUF;
+
+template <int OUT>
+__global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
+                                                       int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[R_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w >> 1, wq = w & 1;
+
+    int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+    constexpr int GM = 8;
+    const int band = t / (GM * tiles_n);
+    const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
+    const int tin = t - band * GM * tiles_n;
+    const int tm = band * GM + tin % gm, tn = tin / gm;
+    const int m0 = tm * R_TILE, n0 = tn * R_TILE;
+
+    // ---- staging: operand tile = 16 pieces of 8 rows x 128 B; wave w issues pieces w*4 .. w*4+3 of P and of Q
+    uint32_t offP[4], offQ[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int piece = w * 4 + jj;
+        const int r = piece * 8 + (lane >> 3);
+        const int src_chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+        const int nl = (n0 + r < N) ? r : (N - 1 - n0);       // clamp: rows past the edge re-read a valid row
+        const int ml = (m0 + r < M) ? r : (M - 1 - m0);
+        offP[jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
+        offQ[jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
+    }
+    const int8_t* gP = W + (int64_t)n0 * ldw;
+    const int8_t* gQ = X + (int64_t)m0 * ldx;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto dma_item = [&](int buf, auto gc) {      // piece g of the next K-tile: 0..3 P, 4..7 Q; the 8th advances the K cursor
+        constexpr int g = decltype(gc)::value;
+        const uint32_t la = smem_base + buf * R_BUF + (g >= 4 ? R_OPER : 0) + (w * 4 + (g & 3)) * 1024;
+        if constexpr (g < 4) glds16_sbase(gP, offP[g], la);
+        else glds16_sbase(gQ, offQ[g - 4], la);
+        if constexpr (g == 7) { gP += FBK; gQ += FBK; }
+    };
+
+    // ---- fragments: P tile i = rows wp*64 + i*16 .. +15, Q tile j = rows wq*64 + j*16 .. +15; k-step ks = 64 bytes
+    const int frow = lane & 15, fchunk = lane >> 4, fkey = (frow >> 1) & 7;
+    uint32_t lP[2], lQ[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fchunk;
+        lP[ks] = (uint32_t)((wp * 64 + frow) * 128 + ((c ^ fkey) * 16));
+        lQ[ks] = (uint32_t)((wq * 64 + frow) * 128 + ((c ^ fkey) * 16)) + R_OPER;
+    }
+    v4i fa[16], fb[16];              // item it: it < 8: P tile it & 3, ks = it >> 2; it >= 8: Q tile it & 3, ks = (it >> 2) & 1
+    auto read_item = [&](int bufoff, v4i (&f)[16], auto ic) {
+        constexpr int it = decltype(ic)::value, ti = it & 3, ks = (it >> 2) & 1;
+        f[it] = *reinterpret_cast<const v4i*>(smem + bufoff + (it < 8 ? lP[ks] : lQ[ks]) + ti * 16 * 128);
+    };
+    v4i acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    const int NT = K / FBK;
+    // ---- prologue: up to 4 tiles in flight, wait for tile 0, read its fragments
+#pragma unroll
+    for (int b = 0; b < R_NBUF; ++b)
+        if (b < NT) static_for<8>([&](auto gc) { dma_item(b, gc); });
+    if (NT >= 4) __builtin_amdgcn_s_waitcnt(0x4078);        // vmcnt(24): 3 tiles may still be in flight
+    else if (NT == 3) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
+    else if (NT == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8)
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    static_for<16>([&](auto ic) { read_item(0, fa, ic); });
+
+    // one K-tile: 32 MFMAs on `cur`; in their shadows the 16 fragment reads of tile kt+1 into `nxt`, then the 8 DMA pieces
+    // of tile kt+4 into the ring slot tile kt just vacated (its fragments are in registers; every wave passed the barrier
+    // after its own lgkmcnt(0)).
+    auto tile = [&](int kt, v4i (&cur)[16], v4i (&nxt)[16]) {
+        const int rem = NT - 1 - kt;                          // tiles after this one
+        if (rem > 0) {
+            // tile kt+1 must have landed: tiles kt+2, kt+3 (8 pieces each per wave) may stay in flight
+            if (rem >= 3) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
+            else if (rem == 2) __builtin_amdgcn_s_waitcnt(0x0078); // vmcnt(8)  lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0)  lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        const int nbuf = ((kt + 1) & 3) * R_BUF;
+        const bool more = rem >= R_NBUF;                      // tile kt+4 exists
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<32>([&](auto xc) {
+            constexpr int x = decltype(xc)::value, ks = x >> 4, i = (x >> 2) & 3, j = x & 3;
+            // accumulators pinned in AGPRs through the asm form: with one wave per SIMD hipcc otherwise splits them between
+            // the two register files and pays 4 v_accvgpr_write + s_nop in front of every other MFMA (measured 44 % -> see DESIGN)
+            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[ks * 4 + i]), "v"(cur[8 + ks * 4 + j]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (x < 16) read_item(nbuf, nxt, xc);      // (last tile: reads a stale slot, values unused)
+            else if constexpr (x < 24) { if (more) dma_item(kt & 3, std::integral_constant<int, x - 16>{}); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    int kt = 0;
+    for (; kt + 1 < NT; kt += 2) { tile(kt, fa, fb); tile(kt + 1, fb, fa); }
+    if (kt < NT) tile(kt, fa, fb);
+
+    // the asm MFMAs are invisible to hipcc's hazard tracking: drain the pipe, then pass every accumulator through an empty
+    // asm so that no v_accvgpr_read can be scheduled above the drain
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+
+    // ---- epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n of one m per accumulator
+    using O = typename OutElem<OUT>::type;
+    constexpr int OB = (int)sizeof(O);
+    O* y = reinterpret_cast<O*>(epi.y);
+    const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
+    const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
+    const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 64;
+    const bool staged = (wm0 + 64 <= M) && (wn0 + 64 <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
+    __builtin_amdgcn_s_barrier();        // every wave is done with the ring: it becomes the staging area
+    if (staged) {
+        constexpr int RB = 64 * OB, CPR = RB / 16, ROW = 256;       // staged row bytes (128 or 256), chunks per row, row stride
+        uint8_t* sw = smem + w * (64 * ROW);
+        const bool bs_vec = (OUT != OUT_I32) && ((reinterpret_cast<uintptr_t>(epi.b_scale) & 15) == 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ml = j * 16 + dcol;
+            float as = 1.0f;
+            if constexpr (OUT != OUT_I32) as = epi.a_scale[wm0 + ml];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nl = i * 16 + drow4;
+                float bs[4] = {1.f, 1.f, 1.f, 1.f}, bf[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (OUT != OUT_I32) {
+                    if (bs_vec) { const v4f v = *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + nl); bs[0] = v[0]; bs[1] = v[1]; bs[2] = v[2]; bs[3] = v[3]; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bs[r] = epi.b_scale[wn0 + nl + r];
+                    }
+                    if (has_bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
+                    }
+                }
+                O o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = epi_convert<OUT>(acc[i][j][r], as, bs[r], bf[r], has_bias);
+                const int boff = nl * OB;
+                uint8_t* d = sw + ml * ROW + ((((boff >> 4) ^ (ml & (CPR - 1))) << 4) | (boff & 15));
+                if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
+                else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private region
+#pragma unroll
+        for (int it = 0; it < CPR; ++it) {                      // 64 rows, 64 / CPR rows per pass
+            const int r = it * (64 / CPR) + lane / CPR, ch = lane % CPR;
+            const v4u v = *reinterpret_cast<const v4u*>(sw + r * ROW + ((ch ^ (r & (CPR - 1))) << 4));
+            *reinterpret_cast<v4u*>(reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + ch * 16) = v;
+        }
+        return;
+    }
+    // direct path (edge tiles / unaligned y): guarded stores from registers, 4 consecutive n at a time when aligned
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = wm0 + j * 16 + dcol;
+        if (m >= M) continue;
+        float as = 1.0f;
+        if constexpr (OUT != OUT_I32) as = epi.a_scale[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nb = wn0 + i * 16 + drow4;
+            if (nb >= N) continue;
+            O o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + r < N ? nb + r : N - 1;
+                float bs = 1.0f, bf = 0.0f;
+                if constexpr (OUT != OUT_I32) {
+                    bs = epi.b_scale[n];
+                    if (has_bias) bf = load_bias<OUT>(epi.bias, n);
+                }
+                o[r] = epi_convert<OUT>(acc[i][j][r], as, bs, bf, has_bias);
+            }
+            O* dst = y + (int64_t)m * epi.ldy + nb;
+            if (nb + 3 < N && vec_ok) {
+                if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+                else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nb + r < N) dst[r] = o[r];
+            }
+        }
+    }
+}
+
+template <int OUT>
+void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
+                         int64_t K, hipStream_t st) {
+    const int tiles_m = (int)((M + R_TILE - 1) / R_TILE), tiles_n = (int)((N + R_TILE - 1) / R_TILE);
+    gemm_s8_ring128<OUT><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+}
+template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_ring128<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_ring128<OUT_I32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+
 #define PQ_INST(OUT, SHAPE, TM, TN) \
     template void launch_gemm_fast<OUT, SHAPE, TM, TN>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 PQ_INST(PQ_BF16, 16, 256, 256) PQ_INST(PQ_FP16, 16, 256, 256) PQ_INST(PQ_F32, 16, 256, 256) PQ_INST(OUT_I32, 16, 256, 256)

@@ -15,6 +15,7 @@ template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*,
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
@@ -40,7 +41,7 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16, V_SP128X128 };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16, V_SP128X128, V_RING128 };
 
 Variant forced_variant() {
     const char* e = getenv("PQ_FORCE_VARIANT");
@@ -50,6 +51,7 @@ Variant forced_variant() {
     if (!strcmp(e, "sp256_32")) return V_SP256_32;
     if (!strcmp(e, "sp128_16")) return V_SP128_16;
     if (!strcmp(e, "sp128x128")) return V_SP128X128;
+    if (!strcmp(e, "ring128")) return V_RING128;
     return V_AUTO;
 }
 
@@ -63,9 +65,10 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
     const int64_t t128sq = ((M + 127) / 128) * ((N + 127) / 128);
-    // even 128-row tiles fill at most half the chip: 128 x 128 tiles (LDS-read-bound, ~2/3 of the 128 x 256 tile's rate per
-    // CU, but twice the blocks).  Measured: k/v 4096x1024x4096 31 -> 25 us, 70B q/o shard 47 (split-K) -> 43 us.
-    if (t128 <= 128 && t128sq > t128) return V_SP128X128;
+    // even 128-row tiles fill at most half the chip: 128 x 128 tiles from a 4-deep DMA ring (gemm_s8_ring128; latency-bound
+    // on operand ingest, ~2/3 of the 128 x 256 tile's rate per CU, but twice the blocks and no slab traffic).  Measured:
+    // k/v 4096x1024x4096 31 -> 24 us, 70B q/o shard 47 (split-K) -> 40 us, 70B down shard 124 (split-K) -> 119 us.
+    if (t128 <= 128 && t128sq > t128) return V_RING128;
     if (t256 <= 160 && t128 > t256 && t128 <= 256) return V_SP128_16;
     return V_SP256_16;
 }
@@ -76,6 +79,7 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
     if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 16, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP128_16) pq::launch_gemm_fast<OUT, 16, 128, 256>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP128X128) pq::launch_gemm_fast<OUT, 16, 128, 128>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP256_32) {
         if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
         else pq::launch_gemm_fast<OUT, 16, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
@@ -246,10 +250,11 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
     const int64_t tiles = tm == 128 ? t128 : t256;
     if (tiles > 128) return 1;
-    // the slab reduction costs ~15 us, and the single-pass alternative for these grids is the 128 x 128 tile: split-K only
-    // pays on long K (measured: 4 slices from K = 8192 when the grid fills a quarter of the chip, 2 slices from K = 16384)
-    if (K < (tiles <= 64 ? 8192 : 16384)) return 1;
-    int s = tiles <= 64 ? 4 : 2;
+    // the slab reduction costs ~15 us, and the single-pass alternative for these grids is the 128 x 128 ring tile: split-K
+    // only pays when the grid fills at most a quarter of the chip and K is long (measured: 4096x512x8192 32 vs 35 us,
+    // 1024x1024x8192 25 vs 34 us; at half-filled grids the ring tile wins at every K)
+    if (tiles > 64 || K < 8192) return 1;
+    int s = 4;
     while (s > 1 && (K % (128 * s) != 0 || K / s < 1024)) s >>= 1;
     *tm_out = tm;
     return s;
@@ -274,7 +279,7 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.
     int tm = 256;
-    const int ks = (v == V_SP256_16 || v == V_SP128_16 || v == V_SP128X128) && forced_variant() == V_AUTO ? splitk_plan(M, N, K, &tm) : 1;
+    const int ks = (v == V_SP256_16 || v == V_SP128_16 || v == V_RING128) && forced_variant() == V_AUTO ? splitk_plan(M, N, K, &tm) : 1;
     if (ks > 1 && workspace != nullptr) {
         const size_t need = (size_t)ks * (size_t)M * (size_t)N * sizeof(int32_t);
         if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -345,6 +350,7 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
         case V_SP256_32: return "sp256_32x32x32";
         case V_SP128_16: return "sp128x256_16x16x64";
         case V_SP128X128: return "sp128x128_16x16x64";
+        case V_RING128: return "ring128_16x16x64";
         default: return "generic64";
     }
 }

@@ -37,7 +37,7 @@ def test_golden_quantize(pq, golden):
     same(pq.dequantize(qc), g["x_coldeq"], "x_coldeq")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128"])
 def test_golden_gemm_and_qlinear(pq, golden, variant, monkeypatch):
     g = golden
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -70,7 +70,7 @@ SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), 
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128"])
 def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
     """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -82,7 +82,7 @@ def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
     same(got, want, f"acc {M}x{N}x{K} {variant}")
 
 
-@pytest.mark.parametrize("variant", ["sp256_16", "sp256_32", "sp128_16", "sp128x128", "generic"])
+@pytest.mark.parametrize("variant", ["sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128", "generic"])
 def test_gemm_identity_asymmetric(pq, variant, monkeypatch):
     """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
     monkeypatch.setenv("PQ_FORCE_VARIANT", variant)
@@ -166,7 +166,7 @@ def test_quant_strided_and_unaligned(pq):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
                                               (512, 1024, 512, 0, False)])
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_32", "sp128_16", "sp128x128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_32", "sp128_16", "sp128x128", "ring128"])
 def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, monkeypatch):
     monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M + N + K + code)
@@ -202,7 +202,7 @@ def test_qlinear_unaligned_scales_and_output(pq):
 
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 8192, 0, True), (512, 1024, 8192, 0, False), (130, 517, 8192, 2, True),
-                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (2304, 1024, 16384, 0, True)])
+                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (1500, 1000, 16384, 0, True)])
 def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
     == the single-pass kernel (PQ_NO_SPLITK)."""

@@ -27,7 +27,7 @@ for M, N, K, name in SHAPES:
     st = torch.cuda.current_stream().cuda_stream
     ops = 2.0 * M * N * K
     row = f"{name:18s} {M:5d} x {N:5d} x {K:5d} "
-    for v in ("sp256_16", "sp128_16", "sp128x128", ""):
+    for v in ("sp128_16", "sp128x128", "ring128", ""):
         os.environ["PQ_FORCE_VARIANT"] = v
         wb = lib.pq_qlinear_workspace_bytes(M, N, K) if v == "" else 0
         wsp = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
