@@ -1,0 +1,137 @@
+// gemm_s8_skinny.hip — K3/K4 for decode-like problems (M <= 64 tokens): y[M,N] = dequant(xq[M,K] . wq[N,K]^T).
+// With so few tokens the GEMM is a streaming read of the int8 weight matrix — HBM-bound, N*K bytes — and the tiled kernels
+// (one 128-row tile per CU, half of every staged K-tile spent on duplicated activation rows, N/128 CUs busy) reach < 1 TB/s.
+// Here every wave streams 16 weight rows STRAIGHT INTO MFMA FRAGMENTS: lane (r = lane & 15, c = lane >> 4) loads the 16 bytes
+// k0 + 16c .. +15 of row n0 + r — exactly the A operand of v_mfma_i32_16x16x64_i8 — so the weights never touch LDS; the
+// few activation rows come the same way from L2.  A workgroup = KS waves that split K between them for one 16-row block
+// (enough waves in flight to cover HBM latency: KS * U KiB per workgroup), reduce their exact int32 partial tiles through
+// LDS and apply QSPEC E1-E4.  Results are bit-identical to every other variant.
+#include "gemm_epilogue.h"
+
+namespace pq {
+
+// k-steps (64 bytes of K each) loaded per batch: U KiB of weights (+ U*MT KiB of activations) in flight per wave, sized so
+// that 16 waves per workgroup stay within 128 VGPRs
+constexpr int sk_batch(int mt) { return mt == 1 ? 8 : (mt == 2 ? 4 : 2); }
+
+template <int OUT, int MT>       // MT: 16-row tiles of activations (M <= 16 * MT)
+__global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
+                                                       int64_t ldw, EpiArgs epi, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sk_smem[];     // [KS][MT][64 lanes] v4i
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), KS = blockDim.x >> 6;
+    const int r = lane & 15, c = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    constexpr int SK_U = sk_batch(MT);
+
+    // this wave's k-steps: a balanced slice of the K / 64 steps
+    const int steps = K >> 6, s0 = (int)((int64_t)steps * w / KS), s1 = (int)((int64_t)steps * (w + 1) / KS);
+    const int nrow = n0 + r < N ? n0 + r : N - 1;                      // clamp: rows past the edge re-read a valid row
+    const int8_t* wp = W + (int64_t)nrow * ldw + c * 16;
+    const int8_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + r < M ? t * 16 + r : M - 1;
+        xp[t] = X + (int64_t)m * ldx + c * 16;
+    }
+    v4i acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
+
+    int s = s0;
+    for (; s + SK_U <= s1; s += SK_U) {
+        v4i fw[SK_U], fx[SK_U][MT];
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u) {
+            fw[u] = *reinterpret_cast<const v4i*>(wp + (int64_t)(s + u) * 64);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[u], fx[u][t], acc[t], 0, 0, 0);
+    }
+    for (; s < s1; ++s) {
+        const v4i fw = *reinterpret_cast<const v4i*>(wp + (int64_t)s * 64);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const v4i fx = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)s * 64);
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx, acc[t], 0, 0, 0);
+        }
+    }
+
+    // ---- exact reduction of the KS partial tiles through LDS, then E1-E4.  D[row <-> n][col <-> m]: the lane holds
+    // n = n0 + 4c .. 4c+3 of token m = 16t + r.
+    v4i* red = reinterpret_cast<v4i*>(sk_smem);
+    if (KS > 1) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[(w * MT + t) * 64 + lane] = acc[t];
+        __syncthreads();
+    }
+    using O = typename OutElem<OUT>::type;
+    O* y = reinterpret_cast<O*>(epi.y);
+    const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
+    for (int t = w; t < MT; t += KS) {                    // wave w finishes tiles w, w + KS, ...
+        v4i sum = acc[0];
+        if (KS > 1) {
+            sum = v4i{0, 0, 0, 0};
+            for (int k = 0; k < KS; ++k) sum += red[(k * MT + t) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < MT; ++q) if (q == t) sum = acc[q];
+        }
+        const int m = t * 16 + r, nb = n0 + c * 4;
+        if (m >= M || nb >= N) continue;
+        float as = 1.0f;
+        if constexpr (OUT != OUT_I32) as = epi.a_scale[m];
+        O o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nb + j < N ? nb + j : N - 1;
+            float bs = 1.0f, bf = 0.0f;
+            if constexpr (OUT != OUT_I32) {
+                bs = epi.b_scale[n];
+                if (has_bias) bf = load_bias<OUT>(epi.bias, n);
+            }
+            o[j] = epi_convert<OUT>(sum[j], as, bs, bf, has_bias);
+        }
+        O* dst = y + (int64_t)m * epi.ldy + nb;
+        const bool vec = (nb + 3 < N) && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
+        if (vec) {
+            if constexpr (sizeof(O) == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+            else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (nb + j < N) dst[j] = o[j];
+        }
+    }
+}
+
+// KS: enough waves for ~8 per CU overall, at least two k-step batches per wave, at most 16 waves per workgroup
+static int skinny_ks(int64_t N, int64_t K, int mt) {
+    const int64_t blocks = (N + 15) / 16, steps = K / 64;
+    int ks = 1;
+    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(mt)) ks <<= 1;
+    return ks;
+}
+
+template <int OUT>
+void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
+                        int64_t K, hipStream_t st) {
+    const int mt = (int)((M + 15) / 16), ks = skinny_ks(N, K, mt);
+    const dim3 grid((unsigned)((N + 15) / 16)), block((unsigned)(ks * 64));
+    const size_t lds = ks > 1 ? (size_t)ks * mt * 64 * sizeof(v4i) : 0;
+    switch (mt) {
+        case 1: gemm_s8_skinny<OUT, 1><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
+        case 2: gemm_s8_skinny<OUT, 2><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
+        case 3: gemm_s8_skinny<OUT, 3><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
+        default: gemm_s8_skinny<OUT, 4><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
+    }
+}
+template void launch_gemm_skinny<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_skinny<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_skinny<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_skinny<OUT_I32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+
+}  // namespace pq

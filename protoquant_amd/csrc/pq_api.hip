@@ -16,6 +16,7 @@ template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, i
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int SHAPE, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
@@ -41,7 +42,7 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16, V_SP128X128, V_RING128 };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY };
 
 Variant forced_variant() {
     const char* e = getenv("PQ_FORCE_VARIANT");
@@ -52,6 +53,7 @@ Variant forced_variant() {
     if (!strcmp(e, "sp128_16")) return V_SP128_16;
     if (!strcmp(e, "sp128x128")) return V_SP128X128;
     if (!strcmp(e, "ring128")) return V_RING128;
+    if (!strcmp(e, "skinny")) return V_SKINNY;
     return V_AUTO;
 }
 
@@ -59,7 +61,12 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     const bool ok = pq::gemm_fast_eligible(a, lda, b, ldb, M, N, K);
     const Variant f = forced_variant();
     if (f == V_GENERIC || !ok) return V_GENERIC;
+    if (f == V_SKINNY) return M <= 64 ? V_SKINNY : V_RING128;      // the skinny kernel holds at most 4 token tiles
     if (f != V_AUTO) return f;
+    // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us
+    // vs 18 us tiled); 2-4 token tiles re-read the activations 2-4x from L2, which only pays while the tiled grid
+    // (N / 128 tiles) cannot fill the chip (measured: N = 4096 12 vs 20 us at M = 64; N = 14336 39 vs 20 us)
+    if (M <= 16 || (M <= 64 && N <= 8192)) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
@@ -80,6 +87,7 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
     else if (v == V_SP128_16) pq::launch_gemm_fast<OUT, 16, 128, 256>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP128X128) pq::launch_gemm_fast<OUT, 16, 128, 128>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_SKINNY) pq::launch_gemm_skinny<OUT>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SP256_32) {
         if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
         else pq::launch_gemm_fast<OUT, 16, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
@@ -245,7 +253,7 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
 // 256 CUs even with 128-row tiles, K is long enough to amortise the extra pass, and the slices stay multiples of 128.
 static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     if (getenv("PQ_NO_SPLITK")) return 1;
-    if (M < 1 || N < 1 || K < 2048) return 1;
+    if (M <= 64 || N < 1 || K < 2048) return 1;    // (M <= 64: the skinny kernel splits K inside the workgroup)
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
     const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
     const int64_t tiles = tm == 128 ? t128 : t256;
@@ -351,6 +359,7 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
         case V_SP128_16: return "sp128x256_16x16x64";
         case V_SP128X128: return "sp128x128_16x16x64";
         case V_RING128: return "ring128_16x16x64";
+        case V_SKINNY: return "skinny_16x16x64";
         default: return "generic64";
     }
 }

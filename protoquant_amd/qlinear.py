@@ -33,8 +33,9 @@ _RETIRED: list = []
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Caller-owned split-K workspace, one growing buffer per device (stream-ordered reuse on the current stream)."""
-    key = (device.type, device.index)
+    """Caller-owned scratch (split-K slabs, the one-call path's codes and scales): one growing buffer per (device, stream) —
+    reuse is ordered by the stream, and two streams never share a buffer."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

@@ -222,6 +222,50 @@ def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     same(pq.qlinear_s8(*args), want, "single-pass y")
 
 
+@pytest.mark.parametrize("M", [1, 2, 7, 16, 17, 32, 33, 48, 64])
+@pytest.mark.parametrize("N,K", [(16, 128), (100, 256), (512, 1024), (4096, 4096), (1000, 2048), (37, 8192), (8192, 1024)])
+def test_skinny_gemm_exact(pq, M, N, K):
+    """Decode-like shapes (M <= 64) run the weight-streaming kernel: full-range int8 operands, exact int32 accumulators
+    (int_mm) and the fused epilogue with bias, all dtypes of output, ragged N and M."""
+    from protoquant_amd import _lib
+    assert _lib.lib().pq_gemm_variant_name(M, N, K, K, K) == b"skinny_16x16x64"
+    rng = np.random.default_rng(M * 7919 + N + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    same(pq.int_mm(ta, tb), acc, "skinny acc")
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    code = (M + N) % 3
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if (M % 2) else None
+    want = Q.epilogue(acc, xs, ws, bv, code)
+    got = pq.qlinear_s8(ta, torch.from_numpy(xs).cuda(), tb, torch.from_numpy(ws).cuda(), to_gpu(bv, code) if bv is not None else None, TD[code])
+    same(got, want, "skinny y")
+
+
+def test_skinny_strided_operands_and_qlinear_module(pq):
+    """Row strides larger than K on both operands, an output view with ld > N, and the module path (K1 + skinny GEMM)."""
+    rng = np.random.default_rng(31)
+    M, N, K = 24, 777, 512
+    abig = rng.integers(-128, 128, (M, K + 128), dtype=np.int8); bbig = rng.integers(-128, 128, (N, K + 256), dtype=np.int8)
+    a, b = abig[:, :K], bbig[:, :K]
+    acc = (a.astype(np.int64) @ b.astype(np.int64).T).astype(np.int32)
+    same(pq.int_mm(torch.from_numpy(abig).cuda()[:, :K], torch.from_numpy(bbig).cuda()[:, :K]), acc, "strided skinny acc")
+    xs = rng.random(M).astype(np.float32); ws = rng.random(N).astype(np.float32)
+    big = torch.empty((M, N + 24), dtype=torch.bfloat16, device="cuda")
+    out = big[:, 8:N + 8]
+    pq.qlinear_s8(torch.from_numpy(abig).cuda()[:, :K], torch.from_numpy(xs).cuda(), torch.from_numpy(bbig).cuda()[:, :K],
+                  torch.from_numpy(ws).cuda(), None, torch.bfloat16, out=out)
+    same(out.contiguous(), Q.epilogue(acc, xs, ws, None, 0), "strided skinny y")
+    torch.manual_seed(7)
+    lin = torch.nn.Linear(1024, 640, bias=True, dtype=torch.bfloat16)
+    x = torch.randn(5, 1024).to(torch.bfloat16)
+    import copy
+    y = pq.qlinear.from_linear(copy.deepcopy(lin).cuda())(x.cuda())
+    wq, wsc = C.quant_rowwise(bits(lin.weight), 0)
+    y_want, _, _, _ = Q.qlinear(bits(x), 0, wq, wsc, bits(lin.bias))
+    same(y, y_want, "qlinear module on a decode batch")
+
+
 @pytest.mark.parametrize("M,N,K,code,bias", [(2048, 11008, 128, 0, True), (4096, 4352, 128, 1, False), (11008, 2048, 128, 0, True),
                                               (2050, 10990, 256, 2, True)])
 def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
