@@ -85,9 +85,24 @@ def cpu_baseline(M, N, K):
             break
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": round(2.0 * M * N * K / med / 1e12, 4), "unit": "TOPS", "cores": torch.get_num_threads(),
+    # the same qlinear on ONE host thread (SURVEY §8d asks for both): two repetitions, best of
+    nthreads = torch.get_num_threads()
+    one = None
+    try:
+        torch.set_num_threads(1)
+        t1 = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            R.qlinear_ref(x, wq, ws, None)
+            t1.append(time.perf_counter() - t0)
+        one = min(t1)
+    finally:
+        torch.set_num_threads(nthreads)
+    return {"value": round(2.0 * M * N * K / med / 1e12, 4), "unit": "TOPS", "cores": nthreads,
             "kind": "port", "sample": f"{len(ts)} reps of the full {M}x{N}x{K} bf16 qlinear (quant+_int_mm+epilogue), median",
-            "ms_per_step": round(med * 1e3, 2), "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops"}
+            "ms_per_step": round(med * 1e3, 2), "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops",
+            "value_1_thread": round(2.0 * M * N * K / one / 1e12, 4) if one else None,
+            "ms_per_step_1_thread": round(one * 1e3, 1) if one else None}
 
 
 def run_mlp(args):
