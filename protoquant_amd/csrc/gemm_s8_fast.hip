@@ -7,8 +7,8 @@
 //     accumulator registers are then consecutive n of ONE output row m.
 //   * wave (wp, wq) = (w>>2, w&3) owns n-range wp*128+[0,128) x m-range wq*64+[0,64), split in
 //     halves hP (64 n) x hQ (32 m): four quadrants of 16 (16x16x64) or 8 (32x32x32) MFMAs.
-//   * LDS: 2 buffers x {P half0, P half1, Q half0, Q half1} x 16 KiB = 128 KiB, one __shared__
-//     array.  A half-tile is [128 rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
+//   * LDS: a ring of K-tiles {P half0, P half1, Q half0, Q half1}: 2 x 64 KiB for the 256 x 256 tile, 3 x 48 KiB for
+//     the 128-row tile, one __shared__ array.  A half-tile is [rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
 //     (measured conflict-free for ds_read_b128 with both MFMA shapes).  Staging is
 //     global_load_lds_dwordx4: the LDS image is lane-linear, the XOR goes on the per-lane SOURCE address.
 //   * ONE s_barrier per K-tile (a barrier round trip costs ~130-150 cycles on this chip, measured; an
@@ -31,13 +31,8 @@ namespace pq {
 
 constexpr int FT = 256;          // tile edge (both m and n)
 constexpr int FBK = 128;         // K bytes per tile step
-constexpr int HALF_BYTES = 128 * FBK;        // 16 KiB
-constexpr int BUF_BYTES = 4 * HALF_BYTES;    // 64 KiB
 constexpr int EPI_ROW = 256;                 // epilogue staging row: 16 chunks of 16 B, chunk c of row r at c ^ (r & 15)
 constexpr int EPI_WAVE = 64 * EPI_ROW;       // 16 KiB per wave
-constexpr int STAGE_BYTES = (8 * EPI_WAVE > 2 * BUF_BYTES) ? 8 * EPI_WAVE : 2 * BUF_BYTES;   // 128 KiB
-constexpr int SCALE_OFF = STAGE_BYTES;        // + 1 KiB row scales (256 f32) + 1 KiB column scales: DMA'd in the prologue
-constexpr int LDS_BYTES = STAGE_BYTES + 2048;
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -84,7 +79,14 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     // dev builds: wave 0 stamps shader cycles + 100 MHz real time around the whole kernel body (own buffer, never an output)
     unsigned long long st_c0 = 0, st_r0 = 0;
     if constexpr (DBG) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
+    // LDS ring: a K-tile is {P half0, P half1, Q half0, Q half1}; the 128-row tile's 48-KiB K-tiles fit three deep (two in
+    // flight while one is read: 2.5 K-tiles of MFMA time for every DMA to land instead of 1.5 — its K-tile is only 1024
+    // MFMA-cycles long, and operands that come from HBM rather than a warm MALL need more than that)
+    constexpr int PHB = (TN / 2) * FBK, QHB = (TM / 2) * FBK;   // bytes of a P / Q half-tile
+    constexpr int BUFB = 2 * PHB + 2 * QHB;                      // 64, 48 or 32 KiB
+    constexpr int NBUF = (TM == 128 && TN == 256) ? 3 : 2;
+    constexpr int SCALE_OFF = (NBUF * BUFB > 8 * EPI_WAVE) ? NBUF * BUFB : 8 * EPI_WAVE;   // ring / epilogue staging below, scales above
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SCALE_OFF + 2048];                // + 1 KiB row scales + 1 KiB column scales
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     for (int ks = 0; ks < NKS; ++ks) {
         const int c = ks * (8 / NKS) + fchunk;
         lP[ks] = (uint32_t)((wp * PWH + frow) * 128 + ((c ^ fkey) * 16));
-        lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * HALF_BYTES;
+        lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * PHB;
     }
 
     using acc_t = typename std::conditional<SHAPE == 16, v4i, v16i>::type;
@@ -192,10 +194,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             constexpr int jj = isQ ? (g - PPW) % QPW : (g < PPW ? g : g - PPW - 2 * QPW);
             if (!no_dma) {
                 if constexpr (isQ) {
-                    const uint32_t la = smem_base + buf * BUF_BYTES + 2 * HALF_BYTES + h * HALF_BYTES + (w * QPW + jj) * 1024;
+                    const uint32_t la = smem_base + buf * BUFB + 2 * PHB + h * QHB + (w * QPW + jj) * 1024;
                     glds16_sbase(gQ, offQ[h][jj], la);
                 } else {
-                    const uint32_t la = smem_base + buf * BUF_BYTES + h * HALF_BYTES + piece_off + jj * 1024;
+                    const uint32_t la = smem_base + buf * BUFB + h * PHB + piece_off + jj * 1024;
                     glds16_sbase(gP, offP[h][jj], la);
                 }
             }
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     // fragment item it: P: i = it % NPI, ks = it / NPI (NPR items); Q: j = it % NQJ, ks = it / NQJ (NQR items)
     auto readP_item = [&](int bufoff, int h, v4i (&f)[NPI][NKS], auto ic) {
         constexpr int it = decltype(ic)::value, i = it % NPI, ks = it / NPI;
-        if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * HALF_BYTES + i * SHAPE * 128);
+        if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * PHB + i * SHAPE * 128);
     };
     auto readQ_item = [&](int bufoff, int h, v4i (&f)[NQJ][NKS], auto ic) {
         constexpr int it = decltype(ic)::value, j = it % NQJ, ks = it / NQJ;
-        if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * HALF_BYTES + j * SHAPE * 128);
+        if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * QHB + j * SHAPE * 128);
     };
     constexpr int NPR = NPI * NKS;               // P fragment reads per half: 8 or 4
     auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<NPR>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
@@ -248,9 +250,13 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     //   --- vmcnt(0) + lgkmcnt(0) + s_barrier: tile kt+1 visible to all, tile kt's buffer free ---
     //   q2: MFMA acc[1][0] (fPb, fQa)   | slots: read P0[kt+1] -> fPa, then DMA tile kt+2
     //   q3: MFMA acc[1][1] (fPb, fQb)   | slots: read Q0[kt+1] -> fQa (free after q2)
-    auto tile = [&](int kt, auto has_next, auto has_next2) {
-        const int bufoff = (kt & 1) * BUF_BYTES;
-        constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value;
+    // flags: next = tile kt+1 exists, next2 = tile kt+2 exists, dma = tile kt+NBUF exists (its DMA is issued here, into the
+    // slot tile kt vacates).  slot = kt % NBUF is carried by the caller.
+    auto tile = [&](int kt, int slot, auto has_next, auto has_next2, auto has_dma) {
+        (void)kt;
+        const int bufoff = slot * BUFB;
+        const int nextoff = (slot + 1 == NBUF ? 0 : slot + 1) * BUFB;
+        constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value, dma = decltype(has_dma)::value;
         mma(acc[0][0], fPa, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (x < NQR) readQ_item(bufoff, 1, fQb, xc);
@@ -260,18 +266,20 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
         });
         if constexpr (next) {
+            // tile kt+1 must have landed; with a 3-deep ring tile kt+2 (NDMA pieces per wave) may stay in flight
             if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+            else if constexpr (NBUF == 3 && next2) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
             else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
             if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
         }
         mma(acc[1][0], fPb, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff ^ BUF_BYTES, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-            if constexpr (next2 && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(kt & 1, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
+            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(nextoff, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+            if constexpr (dma && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(slot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
         });
         mma(acc[1][1], fPb, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < NQR) readQ_item(bufoff ^ BUF_BYTES, 0, fQa, xc);
+            if constexpr (next && x < NQR) readQ_item(nextoff, 0, fQa, xc);
         });
     };
     constexpr std::true_type yes{};
@@ -292,16 +300,26 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         }
     }
     stage_tile(0);
-    if (NT > 1) { stage_tile(1); __builtin_amdgcn_s_waitcnt(0x0070 | NDMA); }   // vmcnt(NDMA) lgkmcnt(0)
-    else { __builtin_amdgcn_s_waitcnt(0x0070); }                          // vmcnt(0) lgkmcnt(0)
+    if (NT > 1) stage_tile(1);
+    if (NBUF == 3 && NT > 2) stage_tile(2);
+    {   // wait for tile 0 only: the other staged tiles stay in flight
+        const int inflight = (NT < NBUF ? NT : NBUF) - 1;
+        if (inflight == 2) __builtin_amdgcn_s_waitcnt(0x0070 | (2 * NDMA));
+        else if (inflight == 1) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+    }
     __builtin_amdgcn_s_barrier();
     readP(0, 0, fPa);
     readQ(0, 0, fQa);
 
-    int kt = 0;
-    for (; kt + 2 < NT; ++kt) tile(kt, yes, yes);
-    if (kt + 1 < NT) { tile(kt, yes, no); ++kt; }
-    tile(kt, no, no);
+    int kt = 0, slot = 0;
+    auto adv = [&]() { ++kt; slot = (slot + 1 == NBUF) ? 0 : slot + 1; };
+    while (kt + NBUF < NT) { tile(kt, slot, yes, yes, yes); adv(); }
+    if constexpr (NBUF == 3) {
+        if (kt + 2 < NT) { tile(kt, slot, yes, yes, no); adv(); }
+    }
+    if (kt + 1 < NT) { tile(kt, slot, yes, no, no); adv(); }
+    tile(kt, slot, no, no, no);
 
     if constexpr (DBG) {
         if (stamps != nullptr && threadIdx.x == 0) {

@@ -8,7 +8,7 @@ lib = L.lib()
 SHAPES = [(4096, 4096, 4096, "cfg2 / 8B q,o"), (2048, 11008, 4096, "cfg3 gate/up"), (2048, 4096, 11008, "cfg3 down"),
           (4096, 1024, 4096, "8B k,v"), (4096, 14336, 4096, "8B gate/up"), (4096, 4096, 14336, "8B down"),
           (4096, 128256, 4096, "lm_head"), (4096, 1024, 8192, "70B q/o shard"), (4096, 3584, 8192, "70B gate/up shard"),
-          (4096, 1024, 28672, "70B down shard"), (4096, 6144, 4096, "8B fused qkv"), (4096, 28672, 4096, "8B fused gate+up"), (32, 512, 512, "cfg1"), (512, 4096, 4096, "M=512"), (8192, 8192, 8192, "8k cube")]
+          (4096, 1024, 28672, "70B down shard"), (2048, 22016, 4096, "cfg3 fused gate+up"), (4096, 6144, 4096, "8B fused qkv"), (4096, 28672, 4096, "8B fused gate+up"), (32, 512, 512, "cfg1"), (512, 4096, 4096, "M=512"), (8192, 8192, 8192, "8k cube")]
 def t(fn, it):
     import time
     t0 = time.time()
