@@ -100,7 +100,7 @@ from hypothesis import given, settings, strategies as st  # noqa: E402
 from hypothesis.extra import numpy as hnp  # noqa: E402
 
 
-@settings(max_examples=60, deadline=None)
+@settings(max_examples=200, deadline=None, derandomize=True)
 @given(hnp.arrays(np.float32, hnp.array_shapes(min_dims=2, max_dims=2, min_side=1, max_side=24),
                   elements=st.floats(-1e4, 1e4, width=32, allow_nan=False, allow_infinity=False)),
        st.sampled_from([0, 1, 2]))
@@ -116,7 +116,8 @@ def test_quantize_properties_hypothesis(xf, dtype):
         finite = np.isfinite(xr).all()
         if finite:
             se = np.expand_dims(s, axis)
-            assert np.all(np.abs(xr - q.astype(np.float32) * se) <= se * 0.5 * (1 + 1e-6) + 1e-30)
+            # half a step, plus the roundings of s = amax/127, of x/s and of q*s (a few ulps of |x|): x/s can sit on a tie
+            assert np.all(np.abs(xr - q.astype(np.float32) * se) <= se * 0.5 + np.abs(xr) * 4e-7 + 1e-30)
             zero = (np.abs(xr).max(axis=axis) == 0)
             assert np.all(s[zero] == 1.0)
 
