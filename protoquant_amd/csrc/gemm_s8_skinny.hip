@@ -6,6 +6,8 @@
 // few activation rows come the same way from L2.  A workgroup = KS waves that split K between them for one 16-row block
 // (enough waves in flight to cover HBM latency: KS * U KiB per workgroup), reduce their exact int32 partial tiles through
 // LDS and apply QSPEC E1-E4.  Results are bit-identical to every other variant.
+#include <cstdlib>
+
 #include "gemm_epilogue.h"
 
 namespace pq {
@@ -14,74 +16,95 @@ namespace pq {
 // that 16 waves per workgroup stay within 128 VGPRs
 constexpr int sk_batch(int mt) { return mt == 1 ? 8 : (mt == 2 ? 4 : 2); }
 
-template <int OUT, int MT>       // MT: 16-row tiles of activations (M <= 16 * MT)
+// RB: 16-row weight blocks per wave.  The direct-to-fragment access pattern (16 segments of 64 B per instruction) tops out
+// near 9.8 TB/s over the whole chip (tools/ubench/l2_ingest), and the activation fragments travel the same path from L2:
+// with RB = 1 and one token tile they take half of it.  RB = 2 reuses every activation fragment for two weight blocks.
+template <int OUT, int MT, int RB>       // MT: 16-row tiles of activations (M <= 16 * MT)
 __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
                                                        int64_t ldw, EpiArgs epi, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sk_smem[];     // [KS][MT][64 lanes] v4i
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), KS = blockDim.x >> 6;
     const int r = lane & 15, c = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    constexpr int SK_U = sk_batch(MT);
+    const int n0 = blockIdx.x * (16 * RB);
+    constexpr int SK_U = sk_batch(MT * RB);
 
     // this wave's k-steps: a balanced slice of the K / 64 steps
     const int steps = K >> 6, s0 = (int)((int64_t)steps * w / KS), s1 = (int)((int64_t)steps * (w + 1) / KS);
-    const int nrow = n0 + r < N ? n0 + r : N - 1;                      // clamp: rows past the edge re-read a valid row
-    const int8_t* wp = W + (int64_t)nrow * ldw + c * 16;
+    const int8_t* wp[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int nrow = n0 + b * 16 + r < N ? n0 + b * 16 + r : N - 1;    // clamp: rows past the edge re-read a valid row
+        wp[b] = W + (int64_t)nrow * ldw + c * 16;
+    }
     const int8_t* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + r < M ? t * 16 + r : M - 1;
         xp[t] = X + (int64_t)m * ldx + c * 16;
     }
-    v4i acc[MT];
+    v4i acc[RB][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[b][t] = v4i{0, 0, 0, 0};
 
     int s = s0;
     for (; s + SK_U <= s1; s += SK_U) {
-        v4i fw[SK_U], fx[SK_U][MT];
+        v4i fw[SK_U][RB], fx[SK_U][MT];
 #pragma unroll
         for (int u = 0; u < SK_U; ++u) {
-            fw[u] = *reinterpret_cast<const v4i*>(wp + (int64_t)(s + u) * 64);
+#pragma unroll
+            for (int b = 0; b < RB; ++b) fw[u][b] = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)(s + u) * 64);
 #pragma unroll
             for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
         }
 #pragma unroll
         for (int u = 0; u < SK_U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[u], fx[u][t], acc[t], 0, 0, 0);
+            for (int b = 0; b < RB; ++b)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[u][b], fx[u][t], acc[b][t], 0, 0, 0);
     }
     for (; s < s1; ++s) {
-        const v4i fw = *reinterpret_cast<const v4i*>(wp + (int64_t)s * 64);
+        v4i fx[MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const v4i fx = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)s * 64);
-            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx, acc[t], 0, 0, 0);
+        for (int t = 0; t < MT; ++t) fx[t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)s * 64);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const v4i fw = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)s * 64);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx[t], acc[b][t], 0, 0, 0);
         }
     }
 
     // ---- exact reduction of the KS partial tiles through LDS, then E1-E4.  D[row <-> n][col <-> m]: the lane holds
     // n = n0 + 4c .. 4c+3 of token m = 16t + r.
     v4i* red = reinterpret_cast<v4i*>(sk_smem);
+    constexpr int NTL = RB * MT;                          // output tiles of this workgroup: tile q = b * MT + t
     if (KS > 1) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) red[(w * MT + t) * 64 + lane] = acc[t];
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) red[(w * NTL + b * MT + t) * 64 + lane] = acc[b][t];
         __syncthreads();
     }
     using O = typename OutElem<OUT>::type;
     O* y = reinterpret_cast<O*>(epi.y);
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
-    for (int t = w; t < MT; t += KS) {                    // wave w finishes tiles w, w + KS, ...
-        v4i sum = acc[0];
+    for (int q = w; q < NTL; q += KS) {                   // wave w finishes tiles w, w + KS, ...
+        const int b = q / MT, t = q - b * MT;
+        v4i sum = acc[0][0];
         if (KS > 1) {
             sum = v4i{0, 0, 0, 0};
-            for (int k = 0; k < KS; ++k) sum += red[(k * MT + t) * 64 + lane];
+            for (int k = 0; k < KS; ++k) sum += red[(k * NTL + q) * 64 + lane];
         } else {
 #pragma unroll
-            for (int q = 0; q < MT; ++q) if (q == t) sum = acc[q];
+            for (int bb = 0; bb < RB; ++bb)
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) if (bb * MT + tt == q) sum = acc[bb][tt];
         }
-        const int m = t * 16 + r, nb = n0 + c * 4;
+        const int m = t * 16 + r, nb = n0 + b * 16 + c * 4;
         if (m >= M || nb >= N) continue;
         float as = 1.0f;
         if constexpr (OUT != OUT_I32) as = epi.a_scale[m];
@@ -109,25 +132,36 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
 }
 
 // KS: enough waves for ~8 per CU overall, at least two k-step batches per wave, at most 16 waves per workgroup
-static int skinny_ks(int64_t N, int64_t K, int mt) {
-    const int64_t blocks = (N + 15) / 16, steps = K / 64;
+static int skinny_ks(int64_t blocks, int64_t K, int tiles) {
+    const int64_t steps = K / 64;
     int ks = 1;
-    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(mt)) ks <<= 1;
+    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(tiles)) ks <<= 1;
     return ks;
 }
+// two weight blocks per wave once that still leaves >= 192 workgroups (measured: N = 6144 10.2 -> 8.3 us at 16 tokens, lm_head
+// 148 -> 124 us; N = 4096 would drop to 128 workgroups: 6.3 -> 8.1 us)
+static bool skinny_rb2(int64_t N) { const char* e = getenv("PQ_SKINNY_RB"); return e ? (*e == '2') : N >= 6144; }
 
 template <int OUT>
 void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
                         int64_t K, hipStream_t st) {
-    const int mt = (int)((M + 15) / 16), ks = skinny_ks(N, K, mt);
-    const dim3 grid((unsigned)((N + 15) / 16)), block((unsigned)(ks * 64));
-    const size_t lds = ks > 1 ? (size_t)ks * mt * 64 * sizeof(v4i) : 0;
-    switch (mt) {
-        case 1: gemm_s8_skinny<OUT, 1><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
-        case 2: gemm_s8_skinny<OUT, 2><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
-        case 3: gemm_s8_skinny<OUT, 3><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
-        default: gemm_s8_skinny<OUT, 4><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); break;
+    const int mt = (int)((M + 15) / 16);
+    const int rb = (mt <= 2 && skinny_rb2(N)) ? 2 : 1;     // (3-4 token tiles x 2 blocks would not fit the register budget)
+    const int64_t blocks = (N + 16 * rb - 1) / (16 * rb);
+    const int ks = skinny_ks(blocks, K, mt * rb);
+    const dim3 grid((unsigned)blocks), block((unsigned)(ks * 64));
+    const size_t lds = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;
+#define PQ_SK(MTv, RBv) gemm_s8_skinny<OUT, MTv, RBv><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K)
+    if (rb == 2) { if (mt == 1) PQ_SK(1, 2); else PQ_SK(2, 2); }
+    else {
+        switch (mt) {
+            case 1: PQ_SK(1, 1); break;
+            case 2: PQ_SK(2, 1); break;
+            case 3: PQ_SK(3, 1); break;
+            default: PQ_SK(4, 1); break;
+        }
     }
+#undef PQ_SK
 }
 template void launch_gemm_skinny<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template void launch_gemm_skinny<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
