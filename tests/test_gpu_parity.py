@@ -775,6 +775,34 @@ def test_rmsnorm_quantize_feeds_fused_qkv(pq):
         pq.rmsnorm_quantize(x.cuda(), wn.cuda()[:100])
 
 
+def test_full_size_cfg3_gated_mlp_fused(pq):
+    """BASELINE config 3 at full size through GatedMLP (fused gate+up GEMM -> silu_mul_quantize -> down): the fused
+    quantisation of the whole 2048 x 11008 intermediate equals the C oracle on the GPU-produced gate/up, bit for bit, and the
+    block output equals the oracle's down projection on 64 sampled token rows."""
+    M, H, I = 2048, 4096, 11008
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(M, H, generator=g).to(torch.bfloat16)
+    ws = {n: (torch.randn(o, i, generator=g) * 0.02).to(torch.bfloat16) for n, (o, i) in
+          (("gate", (I, H)), ("up", (I, H)), ("down", (H, I)))}
+    lins = {}
+    for n, w in ws.items():
+        lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device="cuda", dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(w.cuda())
+        lins[n] = lin
+    mlp = pq.GatedMLP.from_linears(lins["gate"], lins["up"], lins["down"])
+    gate, up = mlp.gate_up(x.cuda())
+    hq = pq.silu_mul_quantize(gate, up)
+    y = mlp.down(hq)
+    same(y, bits(mlp(x.cuda())), "GatedMLP.forward == its parts")
+    want_q, want_s, _ = C.silu_mul_quant_rowwise(bits(gate), bits(up), 0, want_h=False)
+    same(hq.int_data, want_q, "cfg3 fused silu codes"); same(hq.scale, want_s, "cfg3 fused silu scales")
+    rows = np.random.default_rng(2).choice(M, 64, replace=False)
+    dq, ds = C.quant_rowwise(bits(ws["down"]), 0)
+    acc = (want_q[rows].astype(np.int64) @ dq.astype(np.int64).T).astype(np.int32)
+    same(y[torch.from_numpy(rows).cuda()].contiguous(), Q.epilogue(acc, want_s[rows], ds, None, 0), "cfg3 down rows")
+
+
 def test_randomized_shape_sweep(pq):
     """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
     arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""
