@@ -262,7 +262,7 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     // only pays when the grid fills at most a quarter of the chip and K is long (measured: 4096x512x8192 32 vs 35 us,
     // 1024x1024x8192 25 vs 34 us; at half-filled grids the ring tile wins at every K)
     if (tiles > 64 || K < 8192) return 1;
-    int s = 4;
+    int s = (tiles <= 32 && K >= 12288) ? 8 : 4;       // (128 x 4096 x 14336: 40 us with 4 slices, 28 us with 8)
     while (s > 1 && (K % (128 * s) != 0 || K / s < 1024)) s >>= 1;
     *tm_out = tm;
     return s;

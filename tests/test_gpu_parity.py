@@ -202,7 +202,8 @@ def test_qlinear_unaligned_scales_and_output(pq):
 
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 8192, 0, True), (512, 1024, 8192, 0, False), (130, 517, 8192, 2, True),
-                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (1500, 1000, 16384, 0, True)])
+                                              (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (1500, 1000, 16384, 0, True), (128, 1024, 16384, 0, True),
+                                              (200, 2048, 14336, 1, False)])
 def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
     == the single-pass kernel (PQ_NO_SPLITK)."""
