@@ -30,7 +30,10 @@ template <> struct Pair<PQ_BF16> {
 template <> struct Pair<PQ_FP16> {
     typedef _Float16 st2 __attribute__((ext_vector_type(2)));
     __device__ static __forceinline__ v2f unpack(uint32_t w) { return __builtin_convertvector(__builtin_bit_cast(st2, w), v2f); }
-    __device__ static __forceinline__ uint32_t pack(v2f f) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, st2)); }
+    __device__ static __forceinline__ uint32_t pack(v2f f) {
+        asm volatile("" : "+v"(f));     // a materialised f32 pair: no v_fma_mixlo_f16 folding (see Elem<PQ_FP16>::from_f32)
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, st2));
+    }
 };
 
 // QSPEC S1-S5 on NP pairs at once, written stage by stage so that NP independent instructions follow each other: one

@@ -744,6 +744,19 @@ def test_rmsnorm_quant_vs_oracle(pq, code, rows, cols):
         same(qt.int_data, want_q, "q (strided)"); same(qt.scale, want_s, "scale (strided)")
 
 
+@pytest.mark.parametrize("cols", [1025, 2043, 4102])
+def test_rmsnorm_fp16_rounds_to_f32_before_fp16(pq, cols):
+    """QSPEC N5 rounds x*rs to binary32 and THEN to the storage dtype.  hipcc used to fold the multiply and the fp16 conversion
+    into v_fma_mixlo_f16 (one rounding of the exact product) in the ragged-width kernel: ~1 element in 10^4 differed by an ulp
+    where the f32 product sits on an fp16 tie (found by tools/fuzz_quant.py; Elem<PQ_FP16>::from_f32 now pins the f32 value)."""
+    rng = np.random.default_rng(cols)
+    x = Q.from_f32((rng.standard_normal((384, cols)) * rng.choice([0.01, 1.0, 30.0], (384, 1))).astype(np.float32), 1)
+    w = Q.from_f32((1 + 0.2 * rng.standard_normal(cols)).astype(np.float32), 1)
+    want_q, want_s, want_h, _ = C.rmsnorm_quant_rowwise(x, w, 1e-6, 1)
+    qt, h = pq.rmsnorm_quantize(to_gpu(x, 1), to_gpu(w, 1), 1e-6, return_h=True)
+    same(qt.int_data, want_q, "q"); same(qt.scale, want_s, "scale"); _same_h(h, want_h, 1, "h (fp16, ragged width)")
+
+
 def test_rmsnorm_many_rows_pins_sqrt_and_division(pq):
     """65536 rows of 8 values with variances spread over 60 binades: every row exercises the IEEE 1/sqrt(var + eps)."""
     rng = np.random.default_rng(8)
