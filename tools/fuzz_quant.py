@@ -65,6 +65,19 @@ while time.time() - t0 < budget:
     nq, ns, nh, _ = C.rmsnorm_quant_rowwise(x, w, eps, code)
     qt, h = pq.rmsnorm_quantize(xt, to_gpu(w, code), eps, return_h=True)
     bad += eqb(qt.int_data, nq, "K1n q", ctx) + eqb(qt.scale, ns, "K1n s", ctx) + eqb(h, nh, "K1n h", ctx, np.isnan(Q.to_f32(nh, code)))
+    # the fused epilogue (E1-E4) of every GEMM variant the dispatcher may pick at this size, against the numpy oracle
+    M2, N2, K2 = int(rng.integers(1, 400)), int(rng.integers(1, 700)), int(rng.integers(1, 9)) * 128
+    a = rng.integers(-128, 128, (M2, K2), dtype=np.int8); b = rng.integers(-128, 128, (N2, K2), dtype=np.int8)
+    acc = (a.astype(np.int32) @ b.astype(np.int32).T)
+    xs2 = (rng.random(M2).astype(np.float32) + 1e-3) * float(rng.choice([1e-3, 1.0, 50.0])); ws2 = rng.random(N2).astype(np.float32) * 0.02 + 1e-5
+    bv = Q.from_f32(rng.standard_normal(N2).astype(np.float32), code) if rng.random() < 0.5 else None
+    want = Q.epilogue(acc, xs2, ws2, bv, code)
+    for v in ("", "generic", "ring128", "sp256_16"):
+        os.environ["PQ_FORCE_VARIANT"] = v
+        got = pq.qlinear_s8(torch.from_numpy(a).cuda(), torch.from_numpy(xs2).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws2).cuda(),
+                            to_gpu(bv, code) if bv is not None else None, TD[code])
+        bad += eqb(got, want, f"epilogue[{v or 'auto'}]", f"code={code} M={M2} N={N2} K={K2} bias={bv is not None}")
+    os.environ.pop("PQ_FORCE_VARIANT", None)
     n += 1
 print(f"fuzz_quant: {n} problems in {time.time() - t0:.0f} s, mismatches: {bad}")
 print("FUZZ", "CLEAN" if bad == 0 else "FAILED")
