@@ -267,6 +267,20 @@ def test_skinny_strided_operands_and_qlinear_module(pq):
     same(y, y_want, "qlinear module on a decode batch")
 
 
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "skinny"])
+def test_extreme_accumulation_near_int32_limit(pq, variant, monkeypatch):
+    """K = 130944 with every code at -128 on both sides: |acc| = 128^2 * K = 2 145 386 496, 2.1 M short of 2^31 — the
+    accumulators must neither saturate nor wrap, in any variant (skinny: M = 16; the others: M = 192)."""
+    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    K, N = 130944, 320
+    for M in ((16,) if variant == "skinny" else (192,)):
+        a = torch.full((M, K), -128, dtype=torch.int8, device="cuda"); b = torch.full((N, K), -128, dtype=torch.int8, device="cuda")
+        b[1::2] = 127                                   # alternate rows: large negative sums too
+        acc = pq.int_mm(a, b).cpu().numpy()
+        want = np.empty((M, N), np.int64); want[:, 0::2] = 128 * 128 * K; want[:, 1::2] = -128 * 127 * K
+        assert np.array_equal(acc.astype(np.int64), want)
+
+
 @pytest.mark.parametrize("M,N,K,code,bias", [(2048, 11008, 128, 0, True), (4096, 4352, 128, 1, False), (11008, 2048, 128, 0, True),
                                               (2050, 10990, 256, 2, True)])
 def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
