@@ -831,6 +831,47 @@ def test_full_size_cfg3_gated_mlp_fused(pq):
     same(y[torch.from_numpy(rows).cuda()].contiguous(), Q.epilogue(acc, want_s[rows], ds, None, 0), "cfg3 down rows")
 
 
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,pad_q,off_q", [(37, 4096, 64, 0), (9, 1000, 8, 8), (5, 777, 3, 1), (64, 11008, 16, 16), (3, 256, 0, 4)])
+def test_c_abi_strided_code_outputs(pq, code, rows, cols, pad_q, off_q):
+    """The C-ABI's ld_q / ld_out arguments: codes written into a wider, offset buffer (vector and generic paths) by K1, K2,
+    K1s and K1n; dequant reading them back from there.  Bytes outside the [rows, cols] window stay untouched."""
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(rows * 31 + cols + code)
+    x = Q.from_f32((rng.standard_normal((rows, cols)) * 2).astype(np.float32), code)
+    u = Q.from_f32(rng.standard_normal((rows, cols)).astype(np.float32), code)
+    w = Q.from_f32((1 + 0.1 * rng.standard_normal(cols)).astype(np.float32), code)
+    xt, ut, wt = to_gpu(x, code), to_gpu(u, code), to_gpu(w, code)
+    ldq = cols + pad_q + off_q
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fresh():
+        return torch.full((rows, ldq), 77, dtype=torch.int8, device="cuda"), torch.empty(max(rows, cols), dtype=torch.float32, device="cuda")
+
+    def check(qbuf, want_q, what):
+        got = qbuf.cpu().numpy()
+        assert np.array_equal(got[:, off_q:off_q + cols], want_q), what
+        mask = np.ones(got.shape, bool); mask[:, off_q:off_q + cols] = False
+        assert np.all(got[mask] == 77), what + ": wrote outside its window"
+
+    qb, sc = fresh()
+    _lib.check(L.pq_quant_rowwise(xt.data_ptr(), code, rows, cols, cols, qb.data_ptr() + off_q, ldq, sc.data_ptr(), st), "k1")
+    wq, ws = C.quant_rowwise(x, code); check(qb, wq, "K1"); same(sc[:rows], ws, "K1 scale")
+    out = torch.empty((rows, cols + 8), dtype=TD[code], device="cuda")
+    _lib.check(L.pq_dequant(qb.data_ptr() + off_q, ldq, sc.data_ptr(), 1, rows, cols, out.data_ptr(), cols + 8, code, st), "dequant")
+    _same_h(out[:, :cols].contiguous(), C.dequant(wq, ws, 1, code), code, "dequant from a strided code buffer")
+    qb, sc = fresh()
+    _lib.check(L.pq_quant_colwise(xt.data_ptr(), code, rows, cols, cols, qb.data_ptr() + off_q, ldq, sc.data_ptr(), st), "k2")
+    cq, cs = C.quant_colwise(x, code); check(qb, cq, "K2"); same(sc[:cols], cs, "K2 scale")
+    qb, sc = fresh()
+    _lib.check(L.pq_silu_mul_quant_rowwise(xt.data_ptr(), cols, ut.data_ptr(), cols, code, rows, cols, qb.data_ptr() + off_q, ldq, sc.data_ptr(), None, 0, st), "k1s")
+    sq, ss, _ = C.silu_mul_quant_rowwise(x, u, code); check(qb, sq, "K1s"); same(sc[:rows], ss, "K1s scale")
+    qb, sc = fresh()
+    _lib.check(L.pq_rmsnorm_quant_rowwise(xt.data_ptr(), cols, wt.data_ptr(), 1e-5, code, rows, cols, qb.data_ptr() + off_q, ldq, sc.data_ptr(), None, 0, st), "k1n")
+    nq, ns, _, _ = C.rmsnorm_quant_rowwise(x, w, 1e-5, code); check(qb, nq, "K1n"); same(sc[:rows], ns, "K1n scale")
+
+
 def test_randomized_shape_sweep(pq):
     """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
     arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""
