@@ -25,9 +25,17 @@ while time.time() - t0 < budget:
     bias = torch.randn(N, device="cuda").to(dt) if rng.random() < 0.5 else None
     os.environ["PQ_FORCE_VARIANT"] = "generic"
     ref_y = pq.qlinear_s8(a, xs, b, ws, bias, dt).clone(); ref_acc = pq.int_mm(a, b).clone()
+    pad_y, off_y = int(rng.choice([0, 0, 8, 24, 3])), int(rng.choice([0, 0, 8, 1]))
+    ybig = torch.full((M, N + pad_y + off_y), 7.0, dtype=dt, device="cuda")
     for v in VARIANTS:
         os.environ["PQ_FORCE_VARIANT"] = v
-        y = pq.qlinear_s8(a, xs, b, ws, bias, dt); acc = pq.int_mm(a, b)
+        yv = ybig[:, off_y:off_y + N]                  # the output as a window of a wider matrix: ld > N, maybe unaligned
+        pq.qlinear_s8(a, xs, b, ws, bias, dt, out=yv)
+        y = yv.contiguous(); acc = pq.int_mm(a, b)
+        if pad_y + off_y:
+            outside = torch.cat([ybig[:, :off_y], ybig[:, off_y + N:]], dim=1)
+            if not bool((outside == 7.0).all()):
+                bad += 1; print(f"WROTE OUTSIDE variant={v or 'auto'} M={M} N={N} K={K} pad_y={pad_y} off_y={off_y}")
         iv = torch.int32 if dt == torch.float32 else torch.int16
         d = int((y.view(iv) != ref_y.view(iv)).sum()) + int((acc != ref_acc).sum())
         if d:
