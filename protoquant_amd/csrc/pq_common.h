@@ -32,7 +32,7 @@ template <> struct Elem<PQ_FP16> {
     __device__ static __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
     // The empty asm pins f as a rounded binary32 value: without it hipcc folds "f32 multiply, then convert" into
     // v_fma_mixlo_f16, which rounds the exact product ONCE — a different result whenever the f32 product lands on an fp16 tie
-    // (QSPEC rounds to f32 first).  Found by tools/fuzz_quant.py in the RMSNorm kernel; gfx950 has no bf16 counterpart.
+    // (QSPEC rounds to f32 first).  Found by tests/fuzz_quant.py in the RMSNorm kernel; gfx950 has no bf16 counterpart.
     __device__ static __forceinline__ uint16_t from_f32(float f) {
         asm volatile("" : "+v"(f));
         return __builtin_bit_cast(uint16_t, (_Float16)f);

@@ -762,7 +762,7 @@ def test_rmsnorm_quant_vs_oracle(pq, code, rows, cols):
 def test_rmsnorm_fp16_rounds_to_f32_before_fp16(pq, cols):
     """QSPEC N5 rounds x*rs to binary32 and THEN to the storage dtype.  hipcc used to fold the multiply and the fp16 conversion
     into v_fma_mixlo_f16 (one rounding of the exact product) in the ragged-width kernel: ~1 element in 10^4 differed by an ulp
-    where the f32 product sits on an fp16 tie (found by tools/fuzz_quant.py; Elem<PQ_FP16>::from_f32 now pins the f32 value)."""
+    where the f32 product sits on an fp16 tie (found by tests/fuzz_quant.py; Elem<PQ_FP16>::from_f32 now pins the f32 value)."""
     rng = np.random.default_rng(cols)
     x = Q.from_f32((rng.standard_normal((384, cols)) * rng.choice([0.01, 1.0, 30.0], (384, 1))).astype(np.float32), 1)
     w = Q.from_f32((1 + 0.2 * rng.standard_normal(cols)).astype(np.float32), 1)
