@@ -213,11 +213,34 @@ class GatedMLP(nn.Module):
         return self.down(silu_mul_quantize(g, u))
 
 
-def swap_linears(model: nn.Module, predicate=None) -> nn.Module:
-    """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place."""
+def _is_silu(act) -> bool:
+    return isinstance(act, nn.SiLU) or type(act).__name__ in ("SiLU", "SiLUActivation") or act is torch.nn.functional.silu
+
+
+def _as_gated_mlp(mod: nn.Module):
+    """A module shaped like a Llama MLP — Linear children gate_proj / up_proj / down_proj and a SiLU act_fn — as GatedMLP."""
+    g, u, d = (getattr(mod, n, None) for n in ("gate_proj", "up_proj", "down_proj"))
+    if not all(isinstance(l, nn.Linear) for l in (g, u, d)) or not _is_silu(getattr(mod, "act_fn", None)):
+        return None
+    if g.in_features != u.in_features or g.out_features != u.out_features or d.in_features != g.out_features:
+        return None
+    if (g.bias is None) != (u.bias is None):
+        return None
+    return GatedMLP.from_linears(g, u, d)
+
+
+def swap_linears(model: nn.Module, predicate=None, fuse_gated_mlp: bool = False) -> nn.Module:
+    """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place.
+    fuse_gated_mlp=True additionally replaces whole gated-MLP blocks (gate_proj / up_proj / down_proj + SiLU, the
+    Llama-family MLP) by GatedMLP: one fused gate+up GEMM, silu*mul fused into the quantisation, the down GEMM."""
     for name, child in list(model.named_children()):
+        if fuse_gated_mlp and (predicate is None or predicate(name, child)):
+            fused = _as_gated_mlp(child)
+            if fused is not None:
+                setattr(model, name, fused)
+                continue
         if isinstance(child, nn.Linear) and (predicate is None or predicate(name, child)):
             setattr(model, name, qlinear.from_linear(child))
         else:
-            swap_linears(child, predicate)
+            swap_linears(child, predicate, fuse_gated_mlp)
     return model

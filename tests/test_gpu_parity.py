@@ -872,6 +872,34 @@ def test_c_abi_strided_code_outputs(pq, code, rows, cols, pad_q, off_q):
     nq, ns, _, _ = C.rmsnorm_quant_rowwise(x, w, 1e-5, code); check(qb, nq, "K1n"); same(sc[:rows], ns, "K1n scale")
 
 
+def test_swap_linears_on_a_transformers_llama(pq):
+    """A tiny randomly initialised transformers LlamaForCausalLM: swap_linears(fuse_gated_mlp=True) turns every projection into
+    qlinear and every LlamaMLP into GatedMLP; the logits stay close to the bf16 model's (int8 noise only), and the fused MLP
+    block equals the oracle chain bit for bit."""
+    tr = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    cfg = tr.LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=2, max_position_embeddings=128)
+    model = tr.LlamaForCausalLM(cfg).to(torch.bfloat16).cuda().eval()
+    ids = torch.randint(0, 512, (2, 48), device="cuda")
+    with torch.no_grad():
+        ref = model(ids).logits.float()
+        mlp0 = model.model.layers[0].mlp
+        wts = {n: getattr(mlp0, n).weight.detach().cpu().clone() for n in ("gate_proj", "up_proj", "down_proj")}
+        pq.swap_linears(model, predicate=lambda n, m: n != "lm_head", fuse_gated_mlp=True)
+        assert isinstance(model.model.layers[0].mlp, pq.GatedMLP) and isinstance(model.model.layers[1].self_attn.q_proj, pq.qlinear)
+        assert isinstance(model.lm_head, torch.nn.Linear)
+        got = model(ids).logits.float()
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0)
+        assert float(cos) > 0.995, float(cos)
+        x = torch.randn(40, 256, device="cuda").to(torch.bfloat16)
+        y = model.model.layers[0].mlp(x)
+    xq, xs = C.quant_rowwise(bits(x), 0)
+    w = {n: C.quant_rowwise(bits(t), 0) for n, t in wts.items()}
+    hq, hs, _ = C.silu_mul_quant_rowwise(C.qlinear_s8(xq, xs, *w["gate_proj"], None, 0), C.qlinear_s8(xq, xs, *w["up_proj"], None, 0), 0)
+    same(y, C.qlinear_s8(hq, hs, *w["down_proj"], None, 0), "swapped LlamaMLP == oracle chain")
+
+
 def test_randomized_shape_sweep(pq):
     """Seeded sweep: 60 random (M, N, K, dtype, bias) problems — ragged tiles on the MFMA fast path (K % 128 == 0),
     arbitrary K on the generic path — qlinear bits and int32 accumulators vs the oracle."""
