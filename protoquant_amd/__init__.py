@@ -4,8 +4,8 @@ libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eage
 from .qtensor import QTensor, quantize, dequantize, silu_mul_quantize, rmsnorm_quantize
 from .qlinear import qlinear, qlinear_s8, qlinear_dyn, int_mm, swap_linears, FusedQLinear, GatedMLP
 from .sharded import (ColumnShardedQLinear, RcclColumnGather, RcclRowReduceScatter, RowShardedQLinear, ShardedGatedMLP,
-                      gather_columns, reduce_rows, shard_bounds)
+                      gather_columns, gather_columns_overlapped, reduce_rows, shard_bounds)
 
 __all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "qlinear_dyn", "int_mm", "swap_linears", "FusedQLinear", "GatedMLP", "silu_mul_quantize", "rmsnorm_quantize",
            "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds", "RowShardedQLinear", "ShardedGatedMLP",
-           "RcclRowReduceScatter", "reduce_rows"]
+           "RcclRowReduceScatter", "reduce_rows", "gather_columns_overlapped"]

@@ -106,3 +106,40 @@ def test_reduce_rows_world2(M, N):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _ov_worker(rank, world, port, M, n_total, chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from protoquant_amd.sharded import gather_columns_overlapped, shard_bounds
+        lo, hi = shard_bounds(n_total, world, rank)
+        full = torch.arange(M, dtype=torch.float32)[:, None] * 10000 + torch.arange(n_total, dtype=torch.float32)[None, :]
+        calls = []
+
+        def rows(m0, m1):
+            calls.append((m0, m1))
+            return full[m0:m1, lo:hi].clone()
+        y = gather_columns_overlapped(rows, M, n_total, chunks, torch.float32, torch.device("cpu"))
+        ok = torch.equal(y, full) and sum(b - a for a, b in calls) == M and all(b > a for a, b in calls)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,n_total,chunks", [(16, 8, 4), (7, 7, 3), (5, 6, 8), (64, 4096, 2)])
+def test_gather_columns_overlapped_world2(M, n_total, chunks):
+    """Row-chunked, asynchronously issued all-gathers (ragged shards and ragged row blocks, more chunks than rows)
+    rebuild exactly the matrix the one-shot gather does."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ov_worker, args=(r, world, port, M, n_total, chunks, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -400,6 +400,10 @@ def test_column_sharded_world1_matches_unsharded(pq):
         y0 = pq.qlinear.from_linear(lin)(x)
         y1 = pq.ColumnShardedQLinear.from_linear(lin)(x)
         assert y1.shape == y0.shape and torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        for chunks in (2, 3, 7):        # row blocks, each block's all-gather issued asynchronously behind its GEMM
+            y2 = pq.ColumnShardedQLinear.from_linear(lin, overlap_chunks=chunks)(x)
+            torch.cuda.synchronize()
+            assert y2.shape == y0.shape and torch.equal(y0.view(torch.int16), y2.view(torch.int16)), chunks
     finally:
         if created:
             dist.destroy_process_group()
