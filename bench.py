@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tp-chunks", type=int, default=1, help="--mode tp: row blocks whose all-gathers overlap the next block's GEMM")
     ap.add_argument("--tokens", type=int, default=4096, help="llama8b workload: tokens per pass (4096 = BASELINE configs[3] prefill; <= 512 = decode-like, replayed from a hipGraph)")
     ap.add_argument("--norms", action="store_true", help="llama8b workload: also run the two RMSNorms of every layer, fused into the activation quantisation (rmsnorm_quantize)")
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
@@ -308,14 +309,33 @@ def main():
                                   y.data_ptr(), n_local, 0, M, n_local, K, wsp.data_ptr() if wbytes else None, wbytes,
                                   torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
 
+    # --mode tp --tp-chunks k: the rows are cut into k blocks; each block's GEMM is followed at once by its asynchronous
+    # all-gather, so block i's transfer overlaps block i+1's GEMM (RCCL runs on its own stream); k = 1 is the plain step
+    chunks = max(1, args.tp_chunks) if tp else 1
+    bounds = [(M * c // chunks, M * (c + 1) // chunks) for c in range(chunks)]
+    y_parts = [torch.empty((world * (b - a) * n_local,), dtype=torch.bfloat16, device=dev) for a, b in bounds] if tp and chunks > 1 else None
+
+    def k3_rows(a, b):
+        L.check(lib.pq_qlinear_s8(xq.data_ptr() + a * K, K, xs.data_ptr() + 4 * a, wq.data_ptr(), K, ws.data_ptr(), None,
+                                  y.data_ptr() + 2 * a * n_local, n_local, 0, b - a, n_local, K, None, 0,
+                                  torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
+
     def step_eager():
         k1()
+        if tp and chunks > 1:
+            works = []
+            for (a, b), part in zip(bounds, y_parts):
+                k3_rows(a, b)
+                works.append(dist.all_gather_into_tensor(part, y[a:b].view(-1), async_op=True))
+            for wk in works:
+                wk.wait()
+            return
         k3()
         if tp:
             dist.all_gather_into_tensor(y_full, y.view(-1))
 
     # hipGraph capture: S consecutive steps (2 launches each) per replay; the collective of --mode tp stays outside.
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and chunks == 1
     S = 1 if tp else max(1, min(args.graph_steps, args.steps))
     graph = None
     if use_graph:
@@ -412,7 +432,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
         "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
-                   "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" if tp else f"dp{world} over tokens, replicated int8 weights"),
+                   "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" + (f", {chunks} row blocks overlapped" if chunks > 1 else "") if tp else f"dp{world} over tokens, replicated int8 weights"),
                    "launch": (f"hipgraph x{S} steps/replay" if graph is not None else "eager"),
                    "gemm_variant": lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()},
         "roofline": {"bound": "mfma", "kernel": "gemm_s8_sp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
