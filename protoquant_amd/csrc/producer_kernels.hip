@@ -356,22 +356,22 @@ __device__ __forceinline__ float rms_h(float x, float w, float rs) {
     return w * xn;       // the caller rounds to the storage dtype
 }
 
+// one 16-byte vector of x and of the weight -> one 16-byte vector of h (QSPEC N5), two elements per instruction
 template <int DT>
 __device__ __forceinline__ v4u rms_h_vec(const v4u& xv, const v4u& wv, float rs) {
-    constexpr int EPV = 16 / Elem<DT>::kBytes;
-    float f[EPV], wf[EPV];
-    Unpack<DT, EPV>::run(xv, f);
-    Unpack<DT, EPV>::run(wv, wf);
     v4u out;
     if constexpr (DT == PQ_F32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = __builtin_bit_cast(uint32_t, rms_h<DT>(f[j], wf[j], rs));
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t xb = xv[j], wb = wv[j];      // copies first (hipcc quirk with vector-element lvalues)
+            out[j] = __builtin_bit_cast(uint32_t, rms_h<DT>(__builtin_bit_cast(float, xb), __builtin_bit_cast(float, wb), rs));
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = Elem<DT>::from_f32(rms_h<DT>(f[2 * j], wf[2 * j], rs));
-            const uint32_t hi = Elem<DT>::from_f32(rms_h<DT>(f[2 * j + 1], wf[2 * j + 1], rs));
-            out[j] = lo | (hi << 16);
+            const uint32_t xw = xv[j], ww = wv[j];
+            const v2f xn = Pair<DT>::unpack(Pair<DT>::pack(Pair<DT>::unpack(xw) * splat(rs)));
+            out[j] = Pair<DT>::pack(Pair<DT>::unpack(ww) * xn);
         }
     }
     return out;
