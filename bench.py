@@ -36,18 +36,22 @@ PEAK_HBM_GBS = 8000.0       # spec; 6290 GB/s measured copy (MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
-    ap.add_argument("--mode", choices=["dp", "tp"], default="dp")
+    ap.add_argument("--mode", choices=["auto", "dp", "tp"], default="auto",
+                    help="auto: N = 1 -> the qlinear on one GPU; N > 1 -> tp (north_star's column-sharded weight + RCCL all-gather); dp = replicas over tokens")
+    ap.add_argument("--repeats", type=int, default=20, help="timed blocks of exactly --steps steps; the median block is reported")
+    ap.add_argument("--warmup-seconds", type=float, default=1.5, help="untimed warm-up by time after the --warmup steps")
+    ap.add_argument("--torch-gather", action="store_true", help="tp: exchange through torch.distributed instead of libpq_rccl.so")
+    ap.add_argument("--no-dp-leg", action="store_true", help="tp: skip the extra dp figure")
+    ap.add_argument("--no-consistency-check", action="store_true")
     ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b"], default="qlinear",
                     help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph-steps", type=int, default=10, help="steps captured per hipGraph replay (dp mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tp-chunks", type=int, default=1, help="--mode tp: row blocks whose all-gathers overlap the next block's GEMM")
     ap.add_argument("--tokens", type=int, default=4096, help="llama8b workload: tokens per pass (4096 = BASELINE configs[3] prefill; <= 512 = decode-like, replayed from a hipGraph)")
     ap.add_argument("--norms", action="store_true", help="llama8b workload: also run the two RMSNorms of every layer, fused into the activation quantisation (rmsnorm_quantize)")
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
@@ -56,57 +60,80 @@ def parse():
     return ap.parse_args()
 
 
-def ev_time_us(fn, iters):
-    """Average duration of `fn` (one kernel launch) over `iters` back-to-back launches, HIP events on
-    the launch stream."""
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(10):
+def graph_of(fn, n, dev=None):
+    """A hipGraph holding n consecutive calls of fn (launched on torch's current stream at replay)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
         fn()
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    b.synchronize()
-    return a.elapsed_time(b) * 1e3 / iters
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    return g
 
 
-def cpu_baseline(M, N, K):
-    """'protoquant's own CPU path': QSPEC around torch._int_mm on this box's host cores (oracle/torch_ref.py).
-    Bounded sample: a few repetitions of the same M x N x K qlinear."""
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(M, N, K, budget_s=25.0):
+    """'protoquant's own CPU path': QSPEC around torch._int_mm on this box's host cores (oracle/torch_ref.py), the same
+    M x N x K bf16 qlinear as the GPU step.  Thread sweep {1, 8, 16, 32, cores this process may run on}: torch's default
+    (every core of the machine) oversubscribes whatever the container is granted and ran SLOWER than one thread in round 1,
+    so the stated baseline is the best of the sweep, with per-stage times (min and median) at that setting."""
     from oracle import torch_ref as R
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
     wq, ws = R.quantize_ref(w, 1)
-    reps, ts = 6, []
-    R.qlinear_ref(x, wq, ws, None)
-    t_all = time.perf_counter()
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        R.qlinear_ref(x, wq, ws, None)
-        ts.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > 25:
-            break
-    ts.sort()
-    med = ts[len(ts) // 2]
-    # the same qlinear on ONE host thread (SURVEY §8d asks for both): two repetitions, best of
-    nthreads = torch.get_num_threads()
-    one = None
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sweep = sorted({t for t in (1, 8, 16, 32, avail) if t <= avail})
+    default_threads = torch.get_num_threads()
+    ops = 2.0 * M * N * K
+    t_start = time.perf_counter()
+    rows = {}
+
+    def stages():
+        t0 = time.perf_counter(); xq, xs = R.quantize_ref(x, 1)
+        t1 = time.perf_counter(); acc = R.int_gemm_ref(xq, wq)
+        t2 = time.perf_counter(); R.epilogue_ref(acc, xs, ws, None, x.dtype)
+        t3 = time.perf_counter()
+        return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
     try:
-        torch.set_num_threads(1)
-        t1 = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            R.qlinear_ref(x, wq, ws, None)
-            t1.append(time.perf_counter() - t0)
-        one = min(t1)
+        for nt in sweep:
+            torch.set_num_threads(nt)
+            stages()                                   # warm-up (thread pool, oneDNN primitive cache)
+            reps = []
+            while len(reps) < 5 and (len(reps) < 2 or time.perf_counter() - t_start < budget_s * (sweep.index(nt) + 1) / len(sweep)):
+                reps.append(stages())
+            tot = sorted(r[3] for r in reps)
+            rows[nt] = {"reps": len(reps), "ms_median": round(tot[len(tot) // 2] * 1e3, 2), "ms_min": round(tot[0] * 1e3, 2),
+                        "stage_ms_min": {"quantize": round(min(r[0] for r in reps) * 1e3, 2), "int_mm": round(min(r[1] for r in reps) * 1e3, 2),
+                                         "epilogue": round(min(r[2] for r in reps) * 1e3, 2)},
+                        "stage_ms_median": {"quantize": round(sorted(r[0] for r in reps)[len(reps) // 2] * 1e3, 2),
+                                            "int_mm": round(sorted(r[1] for r in reps)[len(reps) // 2] * 1e3, 2),
+                                            "epilogue": round(sorted(r[2] for r in reps)[len(reps) // 2] * 1e3, 2)},
+                        "tops_median": round(ops / tot[len(tot) // 2] / 1e12, 4)}
     finally:
-        torch.set_num_threads(nthreads)
-    return {"value": round(2.0 * M * N * K / med / 1e12, 4), "unit": "TOPS", "cores": nthreads,
-            "kind": "port", "sample": f"{len(ts)} reps of the full {M}x{N}x{K} bf16 qlinear (quant+_int_mm+epilogue), median",
-            "ms_per_step": round(med * 1e3, 2), "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops",
-            "value_1_thread": round(2.0 * M * N * K / one / 1e12, 4) if one else None,
-            "ms_per_step_1_thread": round(one * 1e3, 1) if one else None}
+        torch.set_num_threads(default_threads)
+    best = min(rows, key=lambda t: rows[t]["ms_median"])
+    return {"value": rows[best]["tops_median"], "unit": "TOPS", "cores": best, "kind": "port",
+            "sample": f"{rows[best]['reps']} reps of the full {M}x{N}x{K} bf16 qlinear (quantize + torch._int_mm + epilogue) per thread count, median; best of the sweep",
+            "ms_per_step": rows[best]["ms_median"], "ms_per_step_min": rows[best]["ms_min"],
+            "stage_ms_min": rows[best]["stage_ms_min"], "stage_ms_median": rows[best]["stage_ms_median"],
+            "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops", "host_cpu": host_cpu_model(),
+            "cores_available": avail, "torch_default_threads": default_threads,
+            "thread_sweep_tops_median": {str(t): rows[t]["tops_median"] for t in rows},
+            "thread_sweep_ms_median": {str(t): rows[t]["ms_median"] for t in rows},
+            "value_1_thread": rows[1]["tops_median"] if 1 in rows else None}
 
 
 def run_mlp(args):
@@ -278,95 +305,59 @@ def main():
 
     import protoquant_amd as pq
     from protoquant_amd import _lib as L
+    from protoquant_amd.sharded import shard_bounds
     lib = L.lib()
 
     M, N, K = args.M, args.N, args.K
-    tp = args.mode == "tp" and world > 1
-    n_local = N // world if tp else N
-    # synthetic data: seeded on the CPU generator so every box agrees; rank offsets the seed
-    g = torch.Generator().manual_seed(1234 + (0 if tp else rank))
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
-    gw = torch.Generator().manual_seed(4321)
-    w = (torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16)
-    if tp:
-        w = w[rank * n_local:(rank + 1) * n_local]
-    qw = pq.quantize(w.to(dev))                 # one-time weight quantisation (K1 over W's rows)
-    wq, ws = qw.int_data, qw.scale
-    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
-    xs = torch.empty((M,), dtype=torch.float32, device=dev)
-    y = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
-    y_full = torch.empty((world * M * n_local,), dtype=torch.bfloat16, device=dev) if tp else None
+    # N > 1: north_star's split — W column-sharded over the ranks, the activation replicated, ONE RCCL all-gather of the
+    # bf16 output shards per step (strong scaling: the whole job is ONE M x N x K qlinear).  --mode dp: every rank runs
+    # the whole qlinear on its own batch (weak scaling, no collective); reported as the extra key "dp" in tp runs.
+    mode = args.mode if args.mode != "auto" else ("tp" if world > 1 else "dp")
+    tp = mode == "tp" and world > 1
+    st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
 
-    def k1():
-        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream), "pq_quant_rowwise")
+    def build_step(tp_mode):
+        """(step_fn, k1_fn, gemm_fn, gather_fn or None, n_local, state) for one rank"""
+        lo, hi = shard_bounds(N, world, rank) if tp_mode else (0, N)
+        n_local = hi - lo
+        # synthetic data (SURVEY §8d): seeded on the CPU generator so every box agrees; dp ranks offset the seed
+        g = torch.Generator().manual_seed(1234 + (0 if tp_mode else rank))
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        gw = torch.Generator().manual_seed(4321)
+        w = (torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16)[lo:hi]
+        qw = pq.quantize(w.to(dev))                 # one-time weight quantisation (K1 over W's rows)
+        wq, ws = qw.int_data, qw.scale
+        xq = torch.empty((M, K), dtype=torch.int8, device=dev)
+        xs = torch.empty((M,), dtype=torch.float32, device=dev)
+        y = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
+        wbytes = lib.pq_qlinear_workspace_bytes(M, n_local, K)        # 0 for the headline shape; > 0 for narrow shards (split-K)
+        wsp = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
 
-    wbytes = lib.pq_qlinear_workspace_bytes(M, n_local, K)        # 0 for the headline shape; > 0 for narrow tp shards (split-K)
-    wsp = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+        def k1():
+            L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
 
-    def k3():
-        L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
-                                  y.data_ptr(), n_local, 0, M, n_local, K, wsp.data_ptr() if wbytes else None, wbytes,
-                                  torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
+        def k3():
+            L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
+                                      y.data_ptr(), n_local, 0, M, n_local, K, wsp.data_ptr() if wbytes else None, wbytes, st()), "pq_qlinear_s8")
+        gather, info = None, {}
+        if tp_mode:
+            y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            if args.backend == "nccl" and not args.torch_gather:
+                from protoquant_amd.sharded import RcclColumnGather
+                rg = RcclColumnGather()
+                info = {"exchange": "libpq_rccl.so pq_allgather_cols (ncclAllGather + layout kernel)", "rccl_ranks": rg.comm_ranks()}
 
-    # --mode tp --tp-chunks k: the rows are cut into k blocks; each block's GEMM is followed at once by its asynchronous
-    # all-gather, so block i's transfer overlaps block i+1's GEMM (RCCL runs on its own stream); k = 1 is the plain step
-    chunks = max(1, args.tp_chunks) if tp else 1
-    bounds = [(M * c // chunks, M * (c + 1) // chunks) for c in range(chunks)]
-    y_parts = [torch.empty((world * (b - a) * n_local,), dtype=torch.bfloat16, device=dev) for a, b in bounds] if tp and chunks > 1 else None
+                def gather():
+                    rg.gather_into(y, y_full, N)
+            else:
+                from protoquant_amd.sharded import gather_columns
+                info = {"exchange": f"torch.distributed all_gather_into_tensor ({args.backend}) + layout pass", "rccl_ranks": dist.get_world_size()}
 
-    def k3_rows(a, b):
-        L.check(lib.pq_qlinear_s8(xq.data_ptr() + a * K, K, xs.data_ptr() + 4 * a, wq.data_ptr(), K, ws.data_ptr(), None,
-                                  y.data_ptr() + 2 * a * n_local, n_local, 0, b - a, n_local, K, None, 0,
-                                  torch.cuda.current_stream().cuda_stream), "pq_qlinear_s8")
+                def gather():
+                    y_full.copy_(gather_columns(y, N))
+        return k1, k3, gather, n_local, info, (x, xq, xs, y, wq, ws, wsp)
 
-    def step_eager():
-        k1()
-        if tp and chunks > 1:
-            works = []
-            for (a, b), part in zip(bounds, y_parts):
-                k3_rows(a, b)
-                works.append(dist.all_gather_into_tensor(part, y[a:b].view(-1), async_op=True))
-            for wk in works:
-                wk.wait()
-            return
-        k3()
-        if tp:
-            dist.all_gather_into_tensor(y_full, y.view(-1))
-
-    # hipGraph capture: S consecutive steps (2 launches each) per replay; the collective of --mode tp stays outside.
-    use_graph = not args.no_graph and chunks == 1
-    S = 1 if tp else max(1, min(args.graph_steps, args.steps))
-    graph = None
-    if use_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                k1(); k3()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(S):
-                    k1(); k3()
-        except Exception as e:   # report, never silently change what is measured
-            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
-            graph = None
-    if graph is None:
-        S = 1
-
-    def run_steps(n):
-        """exactly n steps: n // S graph replays of S steps + the remainder eagerly"""
-        if graph is not None:
-            for _ in range(n // S):
-                graph.replay()
-                if tp:
-                    dist.all_gather_into_tensor(y_full, y.view(-1))
-            for _ in range(n % S):
-                step_eager()
-        else:
-            for _ in range(n):
-                step_eager()
+    k1, k3, gather, n_local, xinfo, _keep = build_step(tp)
 
     def fence():
         torch.cuda.synchronize()
@@ -374,84 +365,144 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the step.  Compute (K1 + K3/K4) is replayed from a hipGraph of S steps (host-independent); the collective of a tp
+    # step is issued eagerly behind each step's compute (S = 1 there).
+    K_steps = max(1, args.steps)
+    use_graph = not args.no_graph
+    S = 1 if tp else min(K_steps, 50)
+    g_main = g_rem = None
+    if use_graph:
+        try:
+            g_main = graph_of(lambda: (k1(), k3()), S)
+            if K_steps % S:
+                g_rem = graph_of(lambda: (k1(), k3()), K_steps % S)
+        except Exception as e:   # report, never silently change what is measured
+            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
+            g_main = g_rem = None
+
+    def run_steps(n):
+        """exactly n steps"""
+        if g_main is not None and not tp:
+            for _ in range(n // S):
+                g_main.replay()
+            if n % S:
+                (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(lambda: (k1(), k3()), n % S)).replay()
+            return
+        for _ in range(n):
+            if g_main is not None:
+                g_main.replay()
+            else:
+                k1(); k3()
+            if gather is not None:
+                gather()
+
+    # ---- warm-up: the W steps the caller asked for, then warm-up BY TIME (SURVEY §8d: clocks and caches settle under
+    # ~2 s of this very load; a fresh box otherwise times its own power ramp) — all untimed
     run_steps(args.warmup)
     fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    run_steps(args.steps)
-    e1.record()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.warmup_seconds:
+        run_steps(K_steps)
+        torch.cuda.synchronize()
     fence()
-    dt = time.perf_counter() - t0
-    dt_ev = e0.elapsed_time(e1) * 1e-3
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    # per-kernel durations, live, HIP events on the launch stream: each kernel of the step replayed back-to-back from a
-    # hipGraph (host-independent), on the step's own buffers, right after the timed region
-    def kernel_us(fn, per_graph=10, replays=30):
-        try:
-            s2 = torch.cuda.Stream(); s2.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s2):
-                fn()
-            torch.cuda.current_stream().wait_stream(s2)
-            gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk):
-                for _ in range(per_graph):
-                    fn()
-            for _ in range(5):
-                gk.replay()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(replays):
-                gk.replay()
-            b.record(); b.synchronize()
-            return a.elapsed_time(b) * 1e3 / (per_graph * replays)
-        except Exception as e:
-            print(f"[bench] per-kernel graph timing failed ({e}); eager back-to-back launches", file=sys.stderr)
-            return ev_time_us(fn, 300)
-    # primary figure: eager back-to-back launches (small host gaps, like the K1 gaps of a real step; agrees with the
-    # rocprofv3 kernel-trace average of this command); extra figure: gap-free graph replays (sustained, lower clocks)
-    it = max(50, min(args.steps, 500))
-    t_gemm = ev_time_us(k3, it)
-    t_k1 = ev_time_us(k1, it)
-    t_gemm_sustained = kernel_us(k3)
+    # ---- timed: R blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; per block the MAX over
+    # ranks; the reported step time is the MEDIAN block (min and max are reported too)
+    R = max(1, args.repeats)
+    blocks = []
+    for _ in range(R):
+        fence()
+        t0 = time.perf_counter()
+        run_steps(K_steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        blocks.append(dt)
+    blocks.sort()
+    dt = blocks[len(blocks) // 2]
+
+    # ---- per-kernel durations, live, on the launch stream: each kernel of the step replayed gap-free from its own hipGraph,
+    # on the step's buffers, interleaved with the step graph in the same rounds (same clocks), HIP events around each replay.
+    def ev_us(g, n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); b.synchronize()
+        return a.elapsed_time(b) * 1e3 / n
+    PG = 20
+    gk1, gk3, gst = graph_of(k1, PG), graph_of(k3, PG), graph_of(lambda: (k1(), k3()), PG)
+    for g_ in (gk1, gk3, gst):
+        g_.replay()
     torch.cuda.synchronize()
+    tk1, tk3, tst = [], [], []
+    for _ in range(max(R, 20)):
+        tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
+    med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+    t_gemm, t_k1, t_stepc = med(tk3), med(tk1), med(tst)
+    if tp:
+        fence()
+    consistent = (t_gemm + t_k1) <= 1.05 * t_stepc
+    assert consistent or args.no_consistency_check, \
+        f"inconsistent timings: GEMM {t_gemm:.2f} us + K1 {t_k1:.2f} us > 1.05 x compute step {t_stepc:.2f} us"
 
-    ops_step = 2.0 * M * n_local * K                       # per rank
-    total_ops = ops_step * world * args.steps
-    value = total_ops / dt / 1e12
+    ops_job = 2.0 * M * N * K * (1 if tp else world)       # whole job per step
+    value = ops_job * K_steps / dt / 1e12
     k1_bytes = 3 * M * K + 4 * M                           # read bf16, write s8 + one f32 per row
     gemm_bytes = M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local)
+    gemm_ops = 2.0 * M * n_local * K
+    variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
+    kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<TM=128> (K3+K4)", "ring128": "gemm_s8_ring128 (K3+K4)",
+             "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
+    if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
+        kname += " split-K + splitk_reduce_epilogue"
 
     out = {
         "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
-        "value": round(value, 2), "unit": "TOPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
+        "value": round(value, 2), "unit": "TOPS", "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / K_steps * 1e3, 5), "higher_is_better": True,
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
         "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
-                   "parallelism": (f"tp{world} column-sharded W + RCCL all-gather" + (f", {chunks} row blocks overlapped" if chunks > 1 else "") if tp else f"dp{world} over tokens, replicated int8 weights"),
-                   "launch": (f"hipgraph x{S} steps/replay" if graph is not None else "eager"),
-                   "gemm_variant": lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()},
-        "roofline": {"bound": "mfma", "kernel": "gemm_s8_sp256 (K3+K4)", "achieved": round(2.0 * M * n_local * K / t_gemm / 1e6, 1),
-                     "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(2.0 * M * n_local * K / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
-                     "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_gapfree_replay": round(t_gemm_sustained, 2), "traffic": None,
-                     "algorithmic_bytes": gemm_bytes},
+                   "parallelism": (f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant"
+                                   if tp else f"dp{world} over tokens, replicated int8 weights, no collective"),
+                   "launch": (f"hipgraph x{S} steps/replay" + (", collective eager behind each step" if tp else "") if g_main is not None else "eager"),
+                   "repeats": R, "timed": f"median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks)",
+                   "warmup_seconds": args.warmup_seconds, "gemm_variant": variant, **xinfo},
+        "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
+        "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(gemm_ops / t_gemm / 1e6, 1),
+                     "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
+                     "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_min": round(min(tk3), 2),
+                     "how": f"median of {len(tk3)} hipGraph replays of {PG} back-to-back launches, HIP events on the launch stream (includes the ~1 us kernel boundary; rocprofv3 kernel-trace: profiles/)",
+                     "in_step_us": round(t_stepc - t_k1, 2), "traffic": None, "algorithmic_bytes": gemm_bytes},
         "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1),
                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4),
                        "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes},
-        "event_ms_per_step": round(dt_ev / args.steps * 1e3, 5),
+        "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
     }
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
+    if os.path.exists(tj) and not tp:
         try:
             tr = json.load(open(tj))
             out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
         except Exception:
             pass
+    if tp and not args.no_dp_leg:
+        # extra key: the same ranks as independent replicas over tokens (weak scaling, no collective), short
+        k1d, k3d, _g, _nl, _i, _keep2 = build_step(False)
+        gd = graph_of(lambda: (k1d(), k3d()), PG)
+        for _ in range(10):
+            gd.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(25):
+            gd.replay()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        tt = torch.tensor([d], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / float(tt.item()) / 1e12, 2), "unit": "TOPS", "scaling": "weak",
+                     "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(M, N, K)
     elif rank == 0:
@@ -459,6 +510,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

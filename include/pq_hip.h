@@ -45,6 +45,11 @@ enum { PQ_BF16 = 0, PQ_FP16 = 1, PQ_F32 = 2 };
 int32_t pq_version(void);
 /* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
 const char* pq_last_error(void);
+/* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
+ * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same
+ * names are read ONCE, at the first call into the library; this call changes a switch afterwards (process-wide, not
+ * thread-safe against concurrent launches).  A captured hipGraph keeps the choice that was live at capture time. */
+int32_t pq_set_option(const char* name, const char* value);
 
 /* K1 — per-token dynamic symmetric int8 quantisation: replaces quantize(x) of the contract for an
  * activation x[rows, cols] (amax over cols).  q[rows, cols] int8, scale[rows] f32.   QSPEC Q1-Q6. */
@@ -97,6 +102,17 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       int64_t M, int64_t N, int64_t K,
                       void* workspace, size_t workspace_bytes, void* stream);
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* The same qlinear with the output TRANSPOSED: yt[N, M] (leading dimension ldyt), yt[n][m] bit-identical to pq_qlinear_s8's
+ * y[m][n] (the epilogue keeps QSPEC's order — token scale first — although the tokens are now the GEMM's columns; the bias
+ * runs along rows).  For the column-sharded configuration (SURVEY.md §8(e) option 1): the ranks' yt shards [N/G, M] are row
+ * blocks of yt, so the all-gather is contiguous and needs no layout pass (pq_allgather_rows_t in pq_rccl.h).
+ * Arguments as pq_qlinear_s8 (a, a_scale: activation codes [M, K] and token scales; b, b_scale: weight codes [N, K] and
+ * channel scales); workspace per pq_qlinear_t_workspace_bytes(M, N, K). */
+size_t pq_qlinear_t_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
+                        const float* b_scale, const void* bias, void* yt, int64_t ldyt, int32_t out_dtype, int64_t M,
+                        int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* qlinear.forward in ONE call: y[M,N] = qlinear(x[M,K]) with dynamic per-token quantisation of x (K1), the int8 MFMA GEMM
  * and the fused dequant epilogue, output dtype = input dtype.  Scratch (xq, xs, optional split-K slabs) is carved from

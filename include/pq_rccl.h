@@ -34,6 +34,31 @@ int32_t pq_comm_destroy(void* comm);
 size_t pq_allgather_cols_workspace_bytes(int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype);
 int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void* y_full, int64_t M, int64_t n_shard,
                           int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The same exchange for ANY shard split and leading dimensions: rank r owns the columns shard_bounds(n_total, nranks, r) =
+ * the balanced contiguous split whose first n_total % nranks ranks get one extra column (protoquant_amd/sharded.py);
+ * y_shard[M, width_r] with leading dimension ld_shard, y_full[M, n_total] with leading dimension ld_full.  Ragged or strided
+ * shards are packed to [M, ceil(n_total / nranks)] first (one extra kernel; the pad is never read).
+ * workspace >= pq_allgather_cols_v_workspace_bytes() = (nranks + 1) * M * ceil(n_total / nranks) * sizeof(dtype). */
+size_t pq_allgather_cols_v_workspace_bytes(int32_t nranks, int64_t M, int64_t n_total, int32_t dtype);
+int32_t pq_allgather_cols_v(void* comm, const void* y_shard, int64_t ld_shard, void* y_full, int64_t ld_full, int64_t M,
+                            int64_t n_total, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Overlapped form: the exchange of the row block [m0, m1) runs on the communicator's own side stream, ordered behind
+ * everything already enqueued on compute_stream (the block's GEMM), while the caller goes on launching the next block's
+ * GEMM on compute_stream.  No allocation per call: the side stream and its events are created with the communicator,
+ * every block uses its own slice of the ONE workspace sized for all M rows.  pq_comm_join() makes compute_stream wait for
+ * every exchange issued so far.  xGMI is point-to-point (7 links x ~153 GB/s): at 70B shapes a layer's gather (~190 us) is
+ * longer than its GEMM, so only the last block's transfer stays exposed. */
+int32_t pq_allgather_cols_rows_async(void* comm, const void* y_shard, int64_t ld_shard, void* y_full, int64_t ld_full,
+                                     int64_t M, int64_t m0, int64_t m1, int64_t n_total, int32_t dtype, void* workspace,
+                                     size_t workspace_bytes, void* compute_stream);
+int32_t pq_comm_join(void* comm, void* compute_stream);
+/* Transposed shards (SURVEY.md §8(e) option 1): every rank computed yT_shard[width_r, M] = its rows of y^T (pq_qlinear_s8_t);
+ * row blocks are contiguous, so ONE ncclAllGather (equal shards) or one group of ncclBroadcasts (ragged) builds
+ * yT_full[n_total, M] in place — no staging, no layout kernel. */
+int32_t pq_allgather_rows_t(void* comm, const void* yt_shard, void* yt_full, int64_t n_total, int64_t M, int32_t dtype, void* stream);
+/* ranks of the communicator as RCCL reports them (ncclCommCount) */
+int32_t pq_comm_count(void* comm, int32_t* nranks);
+
 /* the layout-fix kernel alone (stacked[nranks, M, n_shard] -> y_full[M, nranks*n_shard]); exposed for tests */
 int32_t pq_unstack_cols(const void* stacked, void* y_full, int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype,
                         void* stream);

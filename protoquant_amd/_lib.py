@@ -19,7 +19,7 @@ EXPORTS = (
     "pq_version", "pq_last_error", "pq_quant_rowwise", "pq_quant_colwise", "pq_dequant",
     "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes", "pq_gemm_variant_name",
     "pq_selftest_fast_quotient", "pq_qlinear_dyn", "pq_qlinear_dyn_workspace_bytes", "pq_silu_mul_quant_rowwise",
-    "pq_rmsnorm_quant_rowwise",
+    "pq_rmsnorm_quant_rowwise", "pq_set_option", "pq_qlinear_s8_t", "pq_qlinear_t_workspace_bytes",
 )
 
 _lib = None
@@ -56,6 +56,10 @@ def lib() -> ctypes.CDLL:
     L.pq_gemm_s8s8s32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]
     L.pq_qlinear_s8.restype = i32
     L.pq_qlinear_s8.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64, i64, vp, sz, vp]
+    L.pq_qlinear_s8_t.restype = i32
+    L.pq_qlinear_s8_t.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64, i64, vp, sz, vp]
+    L.pq_qlinear_t_workspace_bytes.restype = sz
+    L.pq_qlinear_t_workspace_bytes.argtypes = [i64, i64, i64]
     L.pq_qlinear_dyn_workspace_bytes.restype = sz
     L.pq_qlinear_dyn_workspace_bytes.argtypes = [i64, i64, i64]
     L.pq_qlinear_dyn.restype = i32
@@ -64,6 +68,8 @@ def lib() -> ctypes.CDLL:
     L.pq_silu_mul_quant_rowwise.argtypes = [vp, i64, vp, i64, i32, i64, i64, vp, i64, vp, vp, i64, vp]
     L.pq_rmsnorm_quant_rowwise.restype = i32
     L.pq_rmsnorm_quant_rowwise.argtypes = [vp, i64, vp, ctypes.c_float, i32, i64, i64, vp, i64, vp, vp, i64, vp]
+    L.pq_set_option.restype = i32
+    L.pq_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.pq_selftest_fast_quotient.restype = i32
     L.pq_selftest_fast_quotient.argtypes = [vp, vp, i64, vp, vp]
     if L.pq_version() != ABI_VERSION:
@@ -75,6 +81,13 @@ def lib() -> ctypes.CDLL:
 def check(status: int, what: str):
     if status != 0:
         raise PQError(f"{what} failed (status {status}): {lib().pq_last_error().decode()}")
+
+
+def set_option(name: str, value) -> None:
+    """Change a behaviour switch of the loaded library (pq_set_option): PQ_FORCE_VARIANT, PQ_NO_TAILSPLIT, PQ_NO_SPLITK,
+    PQ_SKINNY_RB.  value None / "" restores the default.  The environment variables are read once at the first call."""
+    v = "" if value is None else str(value)
+    check(lib().pq_set_option(name.encode(), v.encode()), f"pq_set_option({name})")
 
 
 def dtype_code(dt: torch.dtype) -> int:

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libpq_rccl.so")
 UNIQUE_ID_BYTES = 128
 EXPORTS = ("pq_rccl_last_error", "pq_comm_unique_id", "pq_comm_init_rank", "pq_comm_destroy",
            "pq_allgather_cols_workspace_bytes", "pq_allgather_cols", "pq_unstack_cols",
-           "pq_reduce_scatter_rows_workspace_bytes", "pq_reduce_scatter_rows")
+           "pq_reduce_scatter_rows_workspace_bytes", "pq_reduce_scatter_rows", "pq_allgather_cols_v_workspace_bytes",
+           "pq_allgather_cols_v", "pq_allgather_cols_rows_async", "pq_comm_join", "pq_allgather_rows_t", "pq_comm_count")
 _lib = None
 i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 
@@ -44,6 +45,18 @@ def lib() -> ctypes.CDLL:
     L.pq_reduce_scatter_rows_workspace_bytes.argtypes = [i32, i64, i64, i32]
     L.pq_reduce_scatter_rows.restype = i32
     L.pq_reduce_scatter_rows.argtypes = [vp, i32, vp, vp, i64, i64, i32, vp, sz, vp]
+    L.pq_allgather_cols_v_workspace_bytes.restype = sz
+    L.pq_allgather_cols_v_workspace_bytes.argtypes = [i32, i64, i64, i32]
+    L.pq_allgather_cols_v.restype = i32
+    L.pq_allgather_cols_v.argtypes = [vp, vp, i64, vp, i64, i64, i64, i32, vp, sz, vp]
+    L.pq_allgather_cols_rows_async.restype = i32
+    L.pq_allgather_cols_rows_async.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]
+    L.pq_comm_join.restype = i32
+    L.pq_comm_join.argtypes = [vp, vp]
+    L.pq_allgather_rows_t.restype = i32
+    L.pq_allgather_rows_t.argtypes = [vp, vp, vp, i64, i64, i32, vp]
+    L.pq_comm_count.restype = i32
+    L.pq_comm_count.argtypes = [vp, ctypes.POINTER(i32)]
     _lib = L
     return L
 

@@ -13,18 +13,22 @@ struct EpiArgs {
     const void* bias;       // [N] in output dtype, nullable
     void* y;                // [M, ldy]
     int64_t ldy;
+    int32_t flags;          // EPI_* bits; 0 = QSPEC as written: (f32(acc) * a_scale[row]) * b_scale[col] (+ bias[col])
 };
+// The transposed product y^T = Wq . xq^T (pq_qlinear_s8_t: the GEMM's rows are output channels n, its columns tokens m) must
+// still round as QSPEC E2-E3 say — the TOKEN scale first — so the column scale is applied first and the bias runs along rows.
+constexpr int32_t EPI_COL_FIRST = 1, EPI_BIAS_ROWS = 2;
 
 template <int OUT> struct OutElem { using type = typename Elem<OUT>::store_t; };
 template <> struct OutElem<OUT_I32> { using type = int32_t; };
 
 // one accumulator -> one output element value (still in registers)
 template <int OUT>
-__device__ __forceinline__ typename OutElem<OUT>::type epi_convert(int acc, float as, float bs, float bias_f, bool has_bias) {
+__device__ __forceinline__ typename OutElem<OUT>::type epi_convert(int acc, float as, float bs, float bias_f, bool has_bias, bool col_first = false) {
     if constexpr (OUT == OUT_I32) {
         return acc;
     } else {
-        float t = epilogue_val(acc, as, bs);
+        float t = epilogue_val(acc, col_first ? bs : as, col_first ? as : bs);
         if (has_bias) t = t + bias_f;          // separate rounded add (built with -ffp-contract=off)
         return Elem<OUT>::from_f32(t);
     }
@@ -34,6 +38,128 @@ template <int OUT>
 __device__ __forceinline__ float load_bias(const void* bias, int64_t n) {
     if constexpr (OUT == OUT_I32) return 0.0f;
     else return Elem<OUT>::to_f32(reinterpret_cast<const typename Elem<OUT>::store_t*>(bias)[n]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dispatch on the run-time (wave-uniform) bias / order flags to the compile-time specialisations.
+#define PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QTP, PTP, has_bias, flags, ...)                                                          \
+    do {                                                                                                                           \
+        const int bmode_ = !(has_bias) ? 0 : (((flags) & EPI_BIAS_ROWS) ? 2 : 1);                                                   \
+        if (!((flags) & EPI_COL_FIRST)) {                                                                                          \
+            if (bmode_ == 0) epi_staged_block<OUT, NPT, NQT, QTP, PTP, 0, false>(__VA_ARGS__);                                      \
+            else epi_staged_block<OUT, NPT, NQT, QTP, PTP, 1, false>(__VA_ARGS__);                                                  \
+        } else {                                                                                                                   \
+            if (bmode_ == 0) epi_staged_block<OUT, NPT, NQT, QTP, PTP, 0, true>(__VA_ARGS__);                                       \
+            else epi_staged_block<OUT, NPT, NQT, QTP, PTP, 2, true>(__VA_ARGS__);                                                   \
+        }                                                                                                                          \
+    } while (0)
+
+// Staged epilogue of ONE wave's block of 16x16 accumulator tiles (v_mfma_i32_16x16x64_i8 with the weight rows as the first
+// operand): tile (pt, qt) holds, in lane l = 16 q + c, the four consecutive columns n = 16 pt + 4 q .. + 3 of output row
+// m = 16 qt + c.  QSPEC E1-E4 in registers, then a transpose through a wave-private LDS region (so that a store
+// instruction writes whole row segments of up to 256 bytes instead of 8 bytes per lane) and 16-byte global stores.
+//
+// Cost model (measured round 1: the epilogue was ISSUE-bound, ~3000 instructions per wave, not store-bound): everything that
+// does not depend on the tile is hoisted — the column scales and the bias of the wave's NPT column tiles live in registers,
+// the LDS write address is one register per column tile (+ an immediate per row tile), the bias is a template flag.
+// Per 4 outputs: 4 v_cvt_f32_i32, 4 v_pk_mul_f32, (2 v_pk_add_f32,) 2 v_cvt_pk, 1 ds_write.
+//
+// The block is staged in passes of QT_PASS row tiles x PT_PASS column tiles that fit the wave's region
+// (QT_PASS * 16 rows of PT_PASS * 16 * sizeof(out) bytes); LDS operations of one wave execute in order, so a pass may
+// overwrite the region as soon as its reads are issued, and only the write -> read turn waits (lgkmcnt(0)).
+// Swizzle: 16-byte chunk c of staged row r sits at chunk c ^ (r & KM): conflict-free ds_read_b128, 2-way ds_write_b64.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// BIAS: 0 none, 1 along columns (n = 16 pt + 4 q + r), 2 along rows (m = 16 qt + c; EPI_BIAS_ROWS).  SWAP: EPI_COL_FIRST.
+template <int OUT, int NPT, int NQT, int QT_PASS, int PT_PASS, int BIAS, bool SWAP, typename AccFn, typename AsFn, typename BsFn>
+__device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_of, BsFn&& b_scale_of, const void* bias_blk,
+                                                 uint8_t* smem, uint32_t sw_off, uint8_t* y_blk, int64_t ldy_bytes, int lane) {
+    using O = typename OutElem<OUT>::type;
+    constexpr int OB = (int)sizeof(O);
+    constexpr int RBY = PT_PASS * 16 * OB;                // staged row bytes: 128, 256 or 512
+    constexpr int CPR = RBY / 16;                         // 16-byte chunks per staged row
+    constexpr int KM = (CPR < 16 ? CPR : 16) - 1;         // swizzle key mask
+    constexpr int RPI = 64 / CPR;                         // rows per ds_read_b128 / global store instruction: 8, 4 or 2
+    constexpr int CSH = (OB == 2) ? 1 : 2;                // chunk of column tile p (inside a pass) = (p << CSH) | b
+    static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && (RBY == 128 || RBY == 256 || RBY == 512), "epilogue pass shape");
+    const int dcol = lane & 15, q = lane >> 4;
+    const int b = (OB == 2) ? (q >> 1) : q;
+    const uint32_t low = (OB == 2) ? (uint32_t)(q & 1) * 8u : 0u;
+    const uint32_t k2 = (uint32_t)(b ^ (dcol & KM));
+    const uint32_t wbase = sw_off + (uint32_t)dcol * RBY + low;
+    // hoisted per column tile: scales (and bias) of n = 16 pt + 4 q .. + 3
+    v4f bs[NPT], bf[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        bs[pt] = v4f{1.f, 1.f, 1.f, 1.f};
+        bf[pt] = v4f{0.f, 0.f, 0.f, 0.f};
+        if constexpr (OUT != OUT_I32) {
+            bs[pt] = b_scale_of(pt);
+            if constexpr (BIAS == 1) {
+                const O* bp = reinterpret_cast<const O*>(bias_blk) + pt * 16 + q * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bf[pt][r] = Elem<OUT>::to_f32(bp[r]);
+            }
+        }
+    }
+    const int lrow = lane / CPR, ch = lane % CPR;
+    const uint32_t rbase = sw_off + (uint32_t)lrow * RBY;
+    const uint32_t vlane = (uint32_t)lrow * (uint32_t)ldy_bytes + (uint32_t)ch * 16u;
+#pragma unroll
+    for (int qp = 0; qp < NQT / QT_PASS; ++qp) {
+#pragma unroll
+        for (int pp = 0; pp < NPT / PT_PASS; ++pp) {
+#pragma unroll
+            for (int ql = 0; ql < QT_PASS; ++ql) {
+                const int qt = qp * QT_PASS + ql;
+                float as = 1.0f, brow = 0.0f;
+                if constexpr (OUT != OUT_I32) {
+                    as = a_scale_of(qt);
+                    if constexpr (BIAS == 2) brow = Elem<OUT>::to_f32(reinterpret_cast<const O*>(bias_blk)[qt * 16 + dcol]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < PT_PASS; ++pl) {
+                    const int pt = pp * PT_PASS + pl;
+                    const v4i c = acc_of(pt, qt);
+                    uint8_t* d = smem + (wbase + ((((uint32_t)pl << CSH) ^ k2) << 4)) + ql * 16 * RBY;
+                    if constexpr (OUT == OUT_I32) {
+                        *reinterpret_cast<v4i*>(d) = c;
+                    } else {
+                        v2f t0 = {(float)c[0], (float)c[1]}, t1 = {(float)c[2], (float)c[3]};   // E1
+                        if constexpr (!SWAP) {
+                            t0 = t0 * v2f{as, as};                                               // E2 (each lane-op rounds separately)
+                            t1 = t1 * v2f{as, as};
+                            t0 = t0 * v2f{bs[pt][0], bs[pt][1]};                                 // E3
+                            t1 = t1 * v2f{bs[pt][2], bs[pt][3]};
+                        } else {                                                                 // transposed product: the columns are the tokens
+                            t0 = t0 * v2f{bs[pt][0], bs[pt][1]};
+                            t1 = t1 * v2f{bs[pt][2], bs[pt][3]};
+                            t0 = t0 * v2f{as, as};
+                            t1 = t1 * v2f{as, as};
+                        }
+                        if constexpr (BIAS == 1) {                                               // E4: a separate rounded add
+                            t0 = t0 + v2f{bf[pt][0], bf[pt][1]};
+                            t1 = t1 + v2f{bf[pt][2], bf[pt][3]};
+                        } else if constexpr (BIAS == 2) {
+                            t0 = t0 + v2f{brow, brow};
+                            t1 = t1 + v2f{brow, brow};
+                        }
+                        O o[4] = {Elem<OUT>::from_f32(t0[0]), Elem<OUT>::from_f32(t0[1]), Elem<OUT>::from_f32(t1[0]), Elem<OUT>::from_f32(t1[1])};
+                        if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
+                        else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's writes have retired (wave-private region)
+#pragma unroll
+            for (int it = 0; it < QT_PASS * 16 / RPI; ++it) {
+                const int r = it * RPI + lrow;                                  // staged row of this lane
+                const v4u v = *reinterpret_cast<const v4u*>(smem + rbase + it * RPI * RBY + (((uint32_t)(ch ^ (r & KM))) << 4));
+                uint8_t* rowp = y_blk + (int64_t)(qp * QT_PASS * 16 + it * RPI) * ldy_bytes + pp * RBY;   // wave-uniform
+                *reinterpret_cast<v4u*>(rowp + vlane) = v;
+            }
+        }
+    }
 }
 
 }  // namespace pq

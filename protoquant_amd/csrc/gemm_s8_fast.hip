@@ -1,12 +1,13 @@
-// gemm_s8_fast.hip — K3/K4 hot variant for gfx950: s8 x s8 -> s32 on v_mfma_i32_16x16x64_i8 /
-// v_mfma_i32_32x32x32_i8 with the fused row-scale x col-scale dequant epilogue.
+// gemm_s8_fast.hip — K3/K4 hot variant for gfx950: s8 x s8 -> s32 on v_mfma_i32_16x16x64_i8
+// with the fused row-scale x col-scale dequant epilogue.
 //
 // Structure (designed for CDNA4):
 //   * 256 x 256 output tile per workgroup, K step = 128 bytes, 512 threads = 8 waves = 2 per SIMD.
 //   * MFMA roles: first operand P = weight rows (n), second operand Q = activation rows (m); a lane's
 //     accumulator registers are then consecutive n of ONE output row m.
 //   * wave (wp, wq) = (w>>2, w&3) owns n-range wp*128+[0,128) x m-range wq*64+[0,64), split in
-//     halves hP (64 n) x hQ (32 m): four quadrants of 16 (16x16x64) or 8 (32x32x32) MFMAs.
+//     halves hP (64 n) x hQ (32 m): four quadrants of 16 MFMAs.  (A 32x32x32 form of the same kernel held a
+//     lower clock, 1.74 vs 2.07 GHz in a bare MFMA loop, and ran 13 % slower: removed in round 2.)
 //   * LDS: a ring of K-tiles {P half0, P half1, Q half0, Q half1}: 2 x 64 KiB for the 256 x 256 tile, 3 x 48 KiB for
 //     the 128-row tile, one __shared__ array.  A half-tile is [rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
 //     (measured conflict-free for ds_read_b128 with both MFMA shapes).  Staging is
@@ -18,9 +19,12 @@
 //     issued+retired its last read of tile t (so tile t's buffer can be refilled with tile t+2) and
 //     has waited for its own DMA pieces of tile t+1 (so tile t+1 is visible to all after the barrier).
 //     Every DMA therefore has a whole K-tile of MFMA time (~2000 cycles) to land.
-//   * Epilogue: the tile's scales are DMA'd to LDS in the prologue; QSPEC E1-E4 in registers; the tile is
-//     transposed through a wave-private, XOR-swizzled LDS region and written with 16-byte stores as
+//   * Epilogue (gemm_epilogue.h, epi_staged_block): the tile's scales are DMA'd to LDS in the prologue; QSPEC E1-E4 in
+//     registers; the tile is transposed through a wave-private, XOR-swizzled region of the ring slot that the last K-tile
+//     does NOT occupy (no barrier: every wave is past the barrier that freed it) and written with 16-byte stores as
 //     256-byte row segments.
+//   * The first K-tile is entered as soon as its first half (P0, Q0: 32 KiB) has landed; Q1 and P1 are waited for
+//     just before the quadrants that read them (two extra barriers, first tile only).
 //   * Dev builds (make ABLATION=1) add compile-time ablated instantiations + cycle/clock stamps (tools/ablate.py).
 #include <cstdlib>
 #include <type_traits>
@@ -31,19 +35,36 @@ namespace pq {
 
 constexpr int FT = 256;          // tile edge (both m and n)
 constexpr int FBK = 128;         // K bytes per tile step
-constexpr int EPI_ROW = 256;                 // epilogue staging row: 16 chunks of 16 B, chunk c of row r at c ^ (r & 15)
-constexpr int EPI_WAVE = 64 * EPI_ROW;       // 16 KiB per wave
+
+// s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | 0x70 | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+// vmcnt(n) for a run-time n (prologue only): the builtin wants a literal
+__device__ __forceinline__ void wait_vmcnt_lgkm0(int n) {
+    switch (n) {
+#define PQ_W(k) case k: __builtin_amdgcn_s_waitcnt(waitcnt_imm(k, 0)); break;
+        PQ_W(0) PQ_W(1) PQ_W(2) PQ_W(3) PQ_W(4) PQ_W(5) PQ_W(6) PQ_W(7) PQ_W(8) PQ_W(9) PQ_W(10) PQ_W(11) PQ_W(12) PQ_W(13) PQ_W(14) PQ_W(15)
+        PQ_W(16) PQ_W(17) PQ_W(18) PQ_W(19) PQ_W(20) PQ_W(21) PQ_W(22) PQ_W(23) PQ_W(24) PQ_W(25) PQ_W(26) PQ_W(27) PQ_W(28) PQ_W(29) PQ_W(30) PQ_W(31)
+#undef PQ_W
+        default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0)); break;
+    }
+}
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 // LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form: no 64-bit VALU address math beside the MFMAs.
-// base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written and restored inside
-// the statement (cdna guide §5.7).  hipcc does not count this load: the K-loop waits with explicit vmcnt(0).
+// base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written in the same statement that reads it
+// and NOT restored: these kernels contain no compiler-generated user of M0 (every LDS-DMA goes through these helpers;
+// `make asm` + grep m0 confirms) — round 1 saved and restored it around every piece, 16 extra SALU per K-tile per wave.
+// hipcc does not count this load: the K-loop waits with explicit vmcnt.
 __device__ __forceinline__ void glds16_sbase(const int8_t* base, uint32_t voff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+// the same with a per-lane 64-bit source address (scale vectors in the prologue)
+__device__ __forceinline__ void glds16_vaddr(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_addr) : "memory");
 }
 
 // XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
@@ -66,7 +87,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // TN: columns (n) of the output tile, 256 or 128 (with TM = 128 only): a 128 x 128 tile for 1024-wide shards whose grid would
 // otherwise fill half the chip or need split-K.  It needs 32 KiB of DMA and 96 KiB of LDS fragment reads per 512
 // MFMA-cycles, so it runs LDS-read/ingest-bound — but with every CU busy and no slab traffic.
-template <int OUT, int SHAPE, int ABL, int TM = 256, int TN = 256>   // SHAPE: 16 -> 16x16x64, 32 -> 32x32x32; ABL: compile-time ablation (0 = product)
+template <int OUT, int ABL, int TM = 256, int TN = 256>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -74,18 +95,30 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr bool DBG = ABL != 0;
     constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
     constexpr bool no_vmwait = ABL & 32, no_barrier = ABL & 64;   // timing-only: results are wrong
-    constexpr bool no_store = ABL & 128, const_scale = ABL & 256; // epilogue split: skip global stores / skip scale loads
+    constexpr int SHAPE = 16;                                     // v_mfma_i32_16x16x64_i8
     (void)dbg;
-    // dev builds: wave 0 stamps shader cycles + 100 MHz real time around the whole kernel body (own buffer, never an output)
-    unsigned long long st_c0 = 0, st_r0 = 0;
-    if constexpr (DBG) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // dev builds: every wave stamps the chip-wide 100 MHz counter (s_memrealtime) and its shader-cycle counter (s_memtime)
+    // at four points — entry, first MFMA possible, K-loop done, epilogue issued — into a buffer of its own (never an output):
+    // stamps[((block * 8 + wave) * 4 + point) * 2 + {0: realtime, 1: cycles}]
+    auto stamp = [&](int point) {
+        if constexpr (DBG) {
+            if (stamps != nullptr) {
+                const unsigned long long r = __builtin_amdgcn_s_memrealtime(), c = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* d = stamps + (((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + point) * 2;
+                    d[0] = r; d[1] = c;
+                }
+            }
+        }
+    };
+    stamp(0);
     // LDS ring: a K-tile is {P half0, P half1, Q half0, Q half1}; the 128-row tile's 48-KiB K-tiles fit three deep (two in
     // flight while one is read: 2.5 K-tiles of MFMA time for every DMA to land instead of 1.5 — its K-tile is only 1024
     // MFMA-cycles long, and operands that come from HBM rather than a warm MALL need more than that)
     constexpr int PHB = (TN / 2) * FBK, QHB = (TM / 2) * FBK;   // bytes of a P / Q half-tile
     constexpr int BUFB = 2 * PHB + 2 * QHB;                      // 64, 48 or 32 KiB
     constexpr int NBUF = (TM == 128 && TN == 256) ? 3 : 2;
-    constexpr int SCALE_OFF = (NBUF * BUFB > 8 * EPI_WAVE) ? NBUF * BUFB : 8 * EPI_WAVE;   // ring / epilogue staging below, scales above
+    constexpr int SCALE_OFF = NBUF * BUFB;                                                 // ring (and, in a free slot, the epilogue staging) below, scales above
     __shared__ __attribute__((aligned(16))) uint8_t smem[SCALE_OFF + 2048];                // + 1 KiB row scales + 1 KiB column scales
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const int tm = band * GM + tin % gm, tn = tin / gm;
     const int m0 = tm * TM, n0 = tn * TN;
 
-    static_assert(TM == 256 || (TM == 128 && SHAPE == 16), "TM = 128 needs the 16x16x64 shape");
+    static_assert(TM == 256 || TM == 128, "tile rows");
     static_assert(TN == 256 || (TN == 128 && TM == 128), "TN = 128 comes with TM = 128");
     constexpr int PWH = TN / 4;           // P rows per wave per half-tile: 64 or 32
     constexpr int PPW = TN / 128;         // DMA pieces per wave per P half-tile: 2 or 1 (a P half-tile is TN/2 rows)
@@ -143,12 +176,12 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;   // LDS byte address of the array
 
     // ---- fragment read addresses (lane part)
-    constexpr int NPI = (SHAPE == 16) ? PWH / 16 : 2;  // P tiles per wave-half (PWH rows)
-    constexpr int NQJ = (SHAPE == 16) ? QW / 16 : 1;   // Q tiles per wave-half (QW rows)
-    constexpr int NKS = (SHAPE == 16) ? 2 : 4;     // MFMA k-steps per 128-byte row
-    constexpr int NACC = (SHAPE == 16) ? 4 : 16;   // accumulator registers per tile
-    const int frow = (SHAPE == 16) ? (lane & 15) : (lane & 31);
-    const int fchunk = (SHAPE == 16) ? (lane >> 4) : (lane >> 5);
+    constexpr int NPI = PWH / 16;  // P tiles per wave-half (PWH rows)
+    constexpr int NQJ = QW / 16;   // Q tiles per wave-half (QW rows)
+    constexpr int NKS = 2;         // MFMA k-steps per 128-byte row
+    constexpr int NACC = 4;        // accumulator registers per tile
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
     const int fkey = (frow >> 1) & 7;
     uint32_t lP[NKS], lQ[NKS];
 #pragma unroll
@@ -158,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * PHB;
     }
 
-    using acc_t = typename std::conditional<SHAPE == 16, v4i, v16i>::type;
+    using acc_t = v4i;
     acc_t acc[2][2][NPI][NQJ];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -232,8 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         static_for<NM>([&](auto xc) {
             constexpr int x = decltype(xc)::value, ks = x / (NPI * NQJ), i = (x / NQJ) % NPI, j = x % NQJ;
             if (!no_mma) {
-                if constexpr (SHAPE == 16) c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
-                else c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
+                c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             slot(xc);
@@ -252,24 +284,30 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     //   q3: MFMA acc[1][1] (fPb, fQb)   | slots: read Q0[kt+1] -> fQa (free after q2)
     // flags: next = tile kt+1 exists, next2 = tile kt+2 exists, dma = tile kt+NBUF exists (its DMA is issued here, into the
     // slot tile kt vacates).  slot = kt % NBUF is carried by the caller.
+    // Tile 0 only (a wave-uniform branch on kt — a peeled copy of the body made hipcc fold the accumulators' zero into the
+    // first MFMAs' C operand and spill): the prologue waited for P0 and Q0 alone; Q1 and P1 are waited for (and published
+    // with a barrier) right before the quadrants whose shadows read them.  VMA = DMA pieces issued after tile 0's in the
+    // prologue, a compile-time function of the flavour.
     auto tile = [&](int kt, int slot, auto has_next, auto has_next2, auto has_dma) {
-        (void)kt;
         const int bufoff = slot * BUFB;
         const int nextoff = (slot + 1 == NBUF ? 0 : slot + 1) * BUFB;
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value, dma = decltype(has_dma)::value;
+        constexpr int VMA = !next ? 0 : ((NBUF == 3 && next2) ? 2 * NDMA : NDMA);
+        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(VMA + PPW, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }   // Q1 of tile 0 visible
         mma(acc[0][0], fPa, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (x < NQR) readQ_item(bufoff, 1, fQb, xc);
         });
+        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(VMA, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }         // P1 of tile 0 visible
         mma(acc[0][1], fPa, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
         });
         if constexpr (next) {
             // tile kt+1 must have landed; with a 3-deep ring tile kt+2 (NDMA pieces per wave) may stay in flight
-            if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
-            else if constexpr (NBUF == 3 && next2) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
-            else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
+            if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   // lgkmcnt(0) only
+            else if constexpr (NBUF == 3 && next2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(NDMA, 0));
+            else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
             if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
         }
         mma(acc[1][0], fPb, fQa, [&](auto xc) {
@@ -296,19 +334,19 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             int e0 = base + lane * 4;
             e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
             const float* src = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + SCALE_OFF + w * 1024), 16, 0, 0);
+            glds16_vaddr(src, smem_base + SCALE_OFF + w * 1024);     // (one more piece ahead of this wave's tile pieces: waited for with them)
         }
     }
     stage_tile(0);
     if (NT > 1) stage_tile(1);
     if (NBUF == 3 && NT > 2) stage_tile(2);
-    {   // wait for tile 0 only: the other staged tiles stay in flight
-        const int inflight = (NT < NBUF ? NT : NBUF) - 1;
-        if (inflight == 2) __builtin_amdgcn_s_waitcnt(0x0070 | (2 * NDMA));
-        else if (inflight == 1) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
-        else __builtin_amdgcn_s_waitcnt(0x0070);
-    }
+    // wait for the first half of tile 0 only (P0, Q0 — pieces are issued in need order P0 | Q0 | Q1 | P1): the rest of
+    // tile 0 and the other staged tiles stay in flight
+    const int vm_after = ((NT < NBUF ? NT : NBUF) - 1) * NDMA;
+    if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+    else wait_vmcnt_lgkm0(vm_after + NDMA - PPW - QPW);
     __builtin_amdgcn_s_barrier();
+    stamp(1);
     readP(0, 0, fPa);
     readQ(0, 0, fQa);
 
@@ -321,12 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     if (kt + 1 < NT) { tile(kt, slot, yes, no, no); adv(); }
     tile(kt, slot, no, no, no);
 
-    if constexpr (DBG) {
-        if (stamps != nullptr && threadIdx.x == 0) {
-            stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - st_c0;
-            stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
-        }
-    }
+    stamp(2);
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
     if (no_epi) {   // keep the accumulators live, write (almost) nothing
         int sink = 0;
@@ -348,86 +381,36 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr int OB = (int)sizeof(O);
     O* y = reinterpret_cast<O*>(epi.y) + (int64_t)kslice * M * epi.ldy;   // slab of this K-slice (kslices == 1: the output itself)
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
-    const int dcol = (SHAPE == 16) ? (lane & 15) : (lane & 31);            // m inside a Q tile
-    const int drow4 = (SHAPE == 16) ? (lane >> 4) * 4 : (lane >> 5) * 4;   // first of 4 consecutive n (+8g for 32x32)
-    constexpr int NG = (SHAPE == 16) ? 1 : 4;
+    const int dcol = lane & 15;                                             // m inside a Q tile
+    const int drow4 = (lane >> 4) * 4;                                      // first of 4 consecutive n
+    constexpr int NG = 1;
     constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
     constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
     const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;                       // this wave's WM(m) x WN(n) block
 
     // staged path: whole block in range, 16-byte aligned rows
     const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
-                        ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
-    __builtin_amdgcn_s_barrier();     // every wave is done reading the K-loop buffers (uniform: all waves reach it)
+                        ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+                        (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
     if (staged) {
-        uint8_t* sw = smem + w * EPI_WAVE;
-        constexpr int RB = (WN * OB < 256) ? WN * OB : 256;   // staged row: 256 bytes (128 n x 2 B, or 64 n x 4 B), 128 for 64 n x 2 B
-        constexpr int NPASS = WN * OB / RB;               // 2 only for the 128-n block of 4-byte outputs: one hP half per pass
-        constexpr int CPR = RB / 16;                      // 16-byte chunks per staged row (chunk c of row r at c ^ (r & (CPR-1)))
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-            for (int hQ = 0; hQ < 2; ++hQ)
-#pragma unroll
-                for (int j = 0; j < NQJ; ++j) {
-                    const int ml = hQ * QW + j * SHAPE + dcol;
-                    float as = 1.0f;
-                    if constexpr (OUT != OUT_I32 && !const_scale) as = reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * WM + ml];
-#pragma unroll
-                    for (int hP = 0; hP < 2; ++hP) {
-                        if (NPASS == 2 && hP != pass) continue;
-#pragma unroll
-                        for (int i = 0; i < NPI; ++i)
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) {
-                                const int nl = hP * PWH + i * SHAPE + drow4 + 8 * g;      // inside the wave block
-                                const acc_t& c = acc[hP][hQ][i][j];
-                                v4f bs = {1.f, 1.f, 1.f, 1.f};
-                                float bf[4] = {0.f, 0.f, 0.f, 0.f};
-                                if constexpr (OUT != OUT_I32 && !const_scale) {
-                                    bs = *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * WN + nl) * 4);
-                                    if (has_bias) {
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
-                                    }
-                                }
-                                O o[4];
-                                if constexpr (OUT == OUT_I32) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) o[r] = c[g * 4 + r];
-                                } else {
-                                    // E1-E4 on 2-wide vectors: v_pk_mul_f32 / v_pk_add_f32 (each lane-op still rounds separately)
-                                    typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-                                    for (int r = 0; r < 4; r += 2) {
-                                        v2f t = {(float)c[g * 4 + r], (float)c[g * 4 + r + 1]};
-                                        t = t * v2f{as, as};
-                                        t = t * v2f{bs[r], bs[r + 1]};
-                                        if (has_bias) t = t + v2f{bf[r], bf[r + 1]};
-                                        o[r] = Elem<OUT>::from_f32(t[0]);
-                                        o[r + 1] = Elem<OUT>::from_f32(t[1]);
-                                    }
-                                }
-                                const int ncol = (NPASS == 2) ? (nl - pass * 64) : nl;
-                                const int boff = ncol * OB;                              // byte offset inside the 256-B row
-                                uint8_t* d = sw + ml * EPI_ROW + ((((boff >> 4) ^ (ml & (CPR - 1))) << 4) | (boff & 15));
-                                if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
-                                else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
-                            }
-                    }
-                }
-            // wave-private region: only this wave's LDS writes must retire before its reads (no barrier)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < WM * CPR / 64; ++it) {
-                const int r = it * (64 / CPR) + lane / CPR, ch = lane % CPR;
-                const v4u v = *reinterpret_cast<const v4u*>(sw + r * EPI_ROW + ((ch ^ (r & (CPR - 1))) << 4));
-                uint8_t* dst = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + pass * 256 + ch * 16;
-                if constexpr (no_store) { if (v[0] == 0x12345678u && v[3] == 0x0badf00du) *reinterpret_cast<v4u*>(dst) = v; }
-                else *reinterpret_cast<v4u*>(dst) = v;
-            }
-            if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before pass 1 overwrites
-        }
+        // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
+        // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
+        // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
+        constexpr int WREG = BUFB / 8;                                      // 8, 6 or 4 KiB
+        const int last_slot = (NT - 1) % NBUF;
+        const uint32_t sw_off = (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
+        constexpr int NPT = 2 * NPI, NQT = 2 * NQJ;                         // column / row tiles of the wave block
+        constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;      // staged rows of at most 256 bytes
+        constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
+        constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
+        static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= WREG, "epilogue staging region");
+        auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt / NPI][qt / NQJ][pt % NPI][qt % NQJ]; };
+        auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * WM + qt * 16 + dcol]; };
+        auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * WN + pt * 16 + drow4) * 4); };
+        uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0);
+        const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0)) : nullptr;
+        PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane);
+        stamp(3);
         return;
     }
 
@@ -458,9 +441,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                                 float bs = 1.0f, bf = 0.0f;
                                 if constexpr (OUT != OUT_I32) {
                                     bs = epi.b_scale[n + r];
-                                    if (has_bias) bf = load_bias<OUT>(epi.bias, n + r);
+                                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
                                 }
-                                o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias);
+                                o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
                             }
                             if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
                             else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
@@ -471,9 +454,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                                 float bs = 1.0f, bf = 0.0f;
                                 if constexpr (OUT != OUT_I32) {
                                     bs = epi.b_scale[n + r];
-                                    if (has_bias) bf = load_bias<OUT>(epi.bias, n + r);
+                                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
                                 }
-                                dst[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias);
+                                dst[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
                             }
                         }
                     }
@@ -490,22 +473,22 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
-template <int OUT, int SHAPE, int TM, int TN>
+template <int OUT, int TM, int TN>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
                       int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
 #ifdef PQ_ABLATION_BUILD
-    if constexpr (OUT == PQ_BF16 && SHAPE == 16 && TM == 256 && TN == 256) {
+    if constexpr (OUT == PQ_BF16 && TM == 256 && TN == 256) {
         switch (gemm_debug_flags()) {
-#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, SHAPE, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
-            PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(128) PQ_ABL(256) PQ_ABL(384) PQ_ABL(1024)
+#define PQ_ABL(n) case n: gemm_s8_sp256<OUT, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
+            PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(1024)
 #undef PQ_ABL
             default: break;
         }
     }
 #endif
-    gemm_s8_sp256<OUT, SHAPE, 0, TM, TN><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+    gemm_s8_sp256<OUT, 0, TM, TN><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
 }
 
 // ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
@@ -515,8 +498,8 @@ void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64
                             int64_t M, int64_t N, int64_t K, int kslices, hipStream_t st) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
-    EpiArgs epi{nullptr, nullptr, nullptr, slabs, N};
-    gemm_s8_sp256<OUT_I32, 16, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
+    EpiArgs epi{nullptr, nullptr, nullptr, slabs, N, 0};
+    gemm_s8_sp256<OUT_I32, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
 }
 template void launch_gemm_splitk_i32<256>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template void launch_gemm_splitk_i32<128>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
@@ -543,8 +526,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const int32_t* __r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (n + r < N) {
-            const float bf = has_bias ? load_bias<OUT>(epi.bias, n + r) : 0.0f;
-            o[r] = epi_convert<OUT>(acc[r], as, epi.b_scale[n + r], bf, has_bias);
+            const float bf = has_bias ? load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r) : 0.0f;
+            o[r] = epi_convert<OUT>(acc[r], as, epi.b_scale[n + r], bf, has_bias, epi.flags & EPI_COL_FIRST);
         } else o[r] = O{};
     }
     const bool vec_st = full && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
@@ -690,48 +673,21 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
     const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 64;
-    const bool staged = (wm0 + 64 <= M) && (wn0 + 64 <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0);
-    __builtin_amdgcn_s_barrier();        // every wave is done with the ring: it becomes the staging area
+    const bool staged = (wm0 + 64 <= M) && (wn0 + 64 <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+                        (OUT == OUT_I32 || (reinterpret_cast<uintptr_t>(epi.b_scale) & 15) == 0) &&
+                        (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
     if (staged) {
-        constexpr int RB = 64 * OB, CPR = RB / 16, ROW = 256;       // staged row bytes (128 or 256), chunks per row, row stride
-        uint8_t* sw = smem + w * (64 * ROW);
-        const bool bs_vec = (OUT != OUT_I32) && ((reinterpret_cast<uintptr_t>(epi.b_scale) & 15) == 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ml = j * 16 + dcol;
-            float as = 1.0f;
-            if constexpr (OUT != OUT_I32) as = epi.a_scale[wm0 + ml];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nl = i * 16 + drow4;
-                float bs[4] = {1.f, 1.f, 1.f, 1.f}, bf[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (OUT != OUT_I32) {
-                    if (bs_vec) { const v4f v = *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + nl); bs[0] = v[0]; bs[1] = v[1]; bs[2] = v[2]; bs[3] = v[3]; }
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bs[r] = epi.b_scale[wn0 + nl + r];
-                    }
-                    if (has_bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bf[r] = load_bias<OUT>(epi.bias, wn0 + nl + r);
-                    }
-                }
-                O o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = epi_convert<OUT>(acc[i][j][r], as, bs[r], bf[r], has_bias);
-                const int boff = nl * OB;
-                uint8_t* d = sw + ml * ROW + ((((boff >> 4) ^ (ml & (CPR - 1))) << 4) | (boff & 15));
-                if constexpr (OB == 2) *reinterpret_cast<v2u*>(d) = *reinterpret_cast<const v2u*>(o);
-                else *reinterpret_cast<v4u*>(d) = *reinterpret_cast<const v4u*>(o);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private region
-#pragma unroll
-        for (int it = 0; it < CPR; ++it) {                      // 64 rows, 64 / CPR rows per pass
-            const int r = it * (64 / CPR) + lane / CPR, ch = lane % CPR;
-            const v4u v = *reinterpret_cast<const v4u*>(sw + r * ROW + ((ch ^ (r & (CPR - 1))) << 4));
-            *reinterpret_cast<v4u*>(reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + r) * epi.ldy + wn0) + ch * 16) = v;
-        }
+        // staging: this wave's quarter (8 KiB) of the ring slot after the last K-tile's.  The last barrier of the loop is
+        // at the start of tile NT-2; after it only slot (NT-1) & 3 is still read for real (the last tile's prefetch of slot
+        // NT & 3 reads values nobody uses), and no DMA is in flight: no barrier needed.
+        const uint32_t sw_off = (uint32_t)((NT & 3) * R_BUF + w * (R_BUF / 4));
+        constexpr int QT_PASS = (OB == 2) ? 4 : 2;                          // 64 rows x 128 B, or 32 rows x 256 B
+        auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt][qt]; };
+        auto as_of = [&](int qt) { return epi.a_scale[wm0 + qt * 16 + dcol]; };
+        auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + pt * 16 + drow4); };
+        uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0);
+        const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0)) : nullptr;
+        PQ_EPI_STAGED_DISPATCH(OUT, 4, 4, QT_PASS, 4, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane);
         return;
     }
     // direct path (edge tiles / unaligned y): guarded stores from registers, 4 consecutive n at a time when aligned
@@ -753,9 +709,9 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
                 float bs = 1.0f, bf = 0.0f;
                 if constexpr (OUT != OUT_I32) {
                     bs = epi.b_scale[n];
-                    if (has_bias) bf = load_bias<OUT>(epi.bias, n);
+                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n);
                 }
-                o[r] = epi_convert<OUT>(acc[i][j][r], as, bs, bf, has_bias);
+                o[r] = epi_convert<OUT>(acc[i][j][r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
             }
             O* dst = y + (int64_t)m * epi.ldy + nb;
             if (nb + 3 < N && vec_ok) {
@@ -780,12 +736,11 @@ template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*
 template void launch_gemm_ring128<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template void launch_gemm_ring128<OUT_I32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 
-#define PQ_INST(OUT, SHAPE, TM, TN) \
-    template void launch_gemm_fast<OUT, SHAPE, TM, TN>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-PQ_INST(PQ_BF16, 16, 256, 256) PQ_INST(PQ_FP16, 16, 256, 256) PQ_INST(PQ_F32, 16, 256, 256) PQ_INST(OUT_I32, 16, 256, 256)
-PQ_INST(PQ_BF16, 16, 128, 256) PQ_INST(PQ_FP16, 16, 128, 256) PQ_INST(PQ_F32, 16, 128, 256) PQ_INST(OUT_I32, 16, 128, 256)
-PQ_INST(PQ_BF16, 16, 128, 128) PQ_INST(PQ_FP16, 16, 128, 128) PQ_INST(PQ_F32, 16, 128, 128) PQ_INST(OUT_I32, 16, 128, 128)
-PQ_INST(PQ_BF16, 32, 256, 256) PQ_INST(OUT_I32, 32, 256, 256)
+#define PQ_INST(OUT, TM, TN) \
+    template void launch_gemm_fast<OUT, TM, TN>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+PQ_INST(PQ_BF16, 256, 256) PQ_INST(PQ_FP16, 256, 256) PQ_INST(PQ_F32, 256, 256) PQ_INST(OUT_I32, 256, 256)
+PQ_INST(PQ_BF16, 128, 256) PQ_INST(PQ_FP16, 128, 256) PQ_INST(PQ_F32, 128, 256) PQ_INST(OUT_I32, 128, 256)
+PQ_INST(PQ_BF16, 128, 128) PQ_INST(PQ_FP16, 128, 128) PQ_INST(PQ_F32, 128, 128) PQ_INST(OUT_I32, 128, 128)
 #undef PQ_INST
 
 }  // namespace pq

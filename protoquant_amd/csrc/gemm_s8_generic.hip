@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void gemm_s8_generic(const int8_t* __restrict_
                 float bs = 1.0f, bf = 0.0f;
                 if constexpr (OUT != OUT_I32) {
                     bs = epi.b_scale[n];
-                    if (has_bias) bf = load_bias<OUT>(epi.bias, n);
+                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n);
                 }
-                y[m * epi.ldy + n] = epi_convert<OUT>(acc[i][j][r], as, bs, bf, has_bias);
+                y[m * epi.ldy + n] = epi_convert<OUT>(acc[i][j][r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
             }
         }
     }

@@ -115,9 +115,9 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
             float bs = 1.0f, bf = 0.0f;
             if constexpr (OUT != OUT_I32) {
                 bs = epi.b_scale[n];
-                if (has_bias) bf = load_bias<OUT>(epi.bias, n);
+                if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n);
             }
-            o[j] = epi_convert<OUT>(sum[j], as, bs, bf, has_bias);
+            o[j] = epi_convert<OUT>(sum[j], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
         }
         O* dst = y + (int64_t)m * epi.ldy + nb;
         const bool vec = (nb + 3 < N) && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
@@ -140,7 +140,9 @@ static int skinny_ks(int64_t blocks, int64_t K, int tiles) {
 }
 // two weight blocks per wave once that still leaves >= 192 workgroups (measured: N = 6144 10.2 -> 8.3 us at 16 tokens, lm_head
 // 148 -> 124 us; N = 4096 would drop to 128 workgroups: 6.3 -> 8.1 us)
-static bool skinny_rb2(int64_t N) { const char* e = getenv("PQ_SKINNY_RB"); return e ? (*e == '2') : N >= 6144; }
+int g_skinny_rb = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_SKINNY_RB"), or the environment read once in pq_api.hip)
+void set_skinny_rb(int v) { g_skinny_rb = v; }
+static bool skinny_rb2(int64_t N) { return g_skinny_rb ? g_skinny_rb == 2 : N >= 6144; }
 
 template <int OUT>
 void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,

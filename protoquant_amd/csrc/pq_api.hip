@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gemm_epilogue.h"
 
@@ -14,13 +15,14 @@ template <int DT> void silu_mul_quant_dispatch(const void*, int64_t, const void*
 template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template <int OUT, int SHAPE, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 void set_stamp_buffer(unsigned long long*);
+void set_skinny_rb(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -42,20 +44,38 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP256_32, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY };
 
-Variant forced_variant() {
-    const char* e = getenv("PQ_FORCE_VARIANT");
+Variant parse_variant(const char* e) {
     if (!e || !*e) return V_AUTO;
     if (!strcmp(e, "generic")) return V_GENERIC;
     if (!strcmp(e, "sp256_16")) return V_SP256_16;
-    if (!strcmp(e, "sp256_32")) return V_SP256_32;
     if (!strcmp(e, "sp128_16")) return V_SP128_16;
     if (!strcmp(e, "sp128x128")) return V_SP128X128;
     if (!strcmp(e, "ring128")) return V_RING128;
     if (!strcmp(e, "skinny")) return V_SKINNY;
     return V_AUTO;
 }
+
+// Behaviour switches (tests / experiments).  The environment is read ONCE, at the first call into the library (a getenv per
+// launch is host time on the hot path, and a switch that a captured hipGraph freezes must not look live); tests that need
+// another setting within one process use pq_set_option().
+struct Options {
+    int variant = V_AUTO;
+    bool no_tailsplit = false, no_splitk = false;
+};
+Options g_opt;
+std::once_flag g_opt_once;
+const Options& options() {
+    std::call_once(g_opt_once, [] {
+        g_opt.variant = parse_variant(getenv("PQ_FORCE_VARIANT"));
+        g_opt.no_tailsplit = getenv("PQ_NO_TAILSPLIT") != nullptr;
+        g_opt.no_splitk = getenv("PQ_NO_SPLITK") != nullptr;
+        if (const char* e = getenv("PQ_SKINNY_RB")) pq::set_skinny_rb(*e == '2' ? 2 : (*e == '1' ? 1 : 0));
+    });
+    return g_opt;
+}
+Variant forced_variant() { return static_cast<Variant>(options().variant); }
 
 Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     const bool ok = pq::gemm_fast_eligible(a, lda, b, ldb, M, N, K);
@@ -83,15 +103,12 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
 template <int OUT>
 void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
               int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 16, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
-    else if (v == V_SP128_16) pq::launch_gemm_fast<OUT, 16, 128, 256>(a, lda, b, ldb, epi, M, N, K, st);
-    else if (v == V_SP128X128) pq::launch_gemm_fast<OUT, 16, 128, 128>(a, lda, b, ldb, epi, M, N, K, st);
+    if (v == V_SP256_16) pq::launch_gemm_fast<OUT, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_SP128_16) pq::launch_gemm_fast<OUT, 128, 256>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_SP128X128) pq::launch_gemm_fast<OUT, 128, 128>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SKINNY) pq::launch_gemm_skinny<OUT>(a, lda, b, ldb, epi, M, N, K, st);
-    else if (v == V_SP256_32) {
-        if constexpr (OUT == PQ_BF16 || OUT == pq::OUT_I32) pq::launch_gemm_fast<OUT, 32, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
-        else pq::launch_gemm_fast<OUT, 16, 256, 256>(a, lda, b, ldb, epi, M, N, K, st);
-    } else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
+    else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
 }
 
 // Tail split: a grid of T > 256 tiles runs ceil(T/256) rounds of one 256x256 tile per CU, and the last round is as long as
@@ -102,7 +119,7 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
 constexpr double kHalfTileCost = 0.65, kSecondLaunchCost = 0.06;
 
 int tail_split_plan(int64_t M, int64_t N, int64_t* lead) {
-    if (getenv("PQ_NO_TAILSPLIT")) return 0;
+    if (options().no_tailsplit) return 0;
     const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
     if (tiles <= 256) return 0;
     auto rounds = [](int64_t blocks) { return (double)((blocks + 255) / 256); };
@@ -133,12 +150,13 @@ void run_gemm_auto(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int
     pq::EpiArgs tail = epi;
     if (axis == 1) {
         tail.b_scale = epi.b_scale ? epi.b_scale + lead : nullptr;
-        tail.bias = epi.bias ? static_cast<const elem_t*>(epi.bias) + lead : nullptr;
+        tail.bias = (epi.bias && !(epi.flags & pq::EPI_BIAS_ROWS)) ? static_cast<const elem_t*>(epi.bias) + lead : epi.bias;
         tail.y = static_cast<elem_t*>(epi.y) + lead;
         run_gemm<OUT>(V_SP256_16, a, lda, b, ldb, epi, M, lead, K, st);
         run_gemm<OUT>(V_SP128_16, a, lda, b + lead * ldb, ldb, tail, M, N - lead, K, st);
     } else {
         tail.a_scale = epi.a_scale ? epi.a_scale + lead : nullptr;
+        tail.bias = (epi.bias && (epi.flags & pq::EPI_BIAS_ROWS)) ? static_cast<const elem_t*>(epi.bias) + lead : epi.bias;
         tail.y = static_cast<elem_t*>(epi.y) + lead * epi.ldy;
         run_gemm<OUT>(V_SP256_16, a, lda, b, ldb, epi, lead, N, K, st);
         run_gemm<OUT>(V_SP128_16, a + lead * lda, lda, b, ldb, tail, M - lead, N, K, st);
@@ -154,6 +172,17 @@ bool bad_mat(const void* p, int64_t rows, int64_t cols, int64_t ld) {
 extern "C" {
 
 int32_t pq_version(void) { return PQ_ABI_VERSION; }
+
+int32_t pq_set_option(const char* name, const char* value) {
+    if (!name) return fail(PQ_ERR_BAD_ARG, "pq_set_option: null name");
+    options();                                   // the environment is consumed first, so a later call_once cannot undo this
+    if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
+    else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
+    else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
+    else return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
+    return PQ_OK;
+}
 const char* pq_last_error(void) { return g_err; }
 
 int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, int8_t* q,
@@ -244,7 +273,7 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
     if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(c, M, N, ldc))
         return fail(PQ_ERR_BAD_ARG, "pq_gemm_s8s8s32: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldc);
     if (M == 0 || N == 0) return PQ_OK;
-    pq::EpiArgs epi{nullptr, nullptr, nullptr, c, ldc};
+    pq::EpiArgs epi{nullptr, nullptr, nullptr, c, ldc, 0};
     run_gemm_auto<pq::OUT_I32>(pick_variant(a, lda, b, ldb, M, N, K), a, lda, b, ldb, epi, M, N, K, static_cast<hipStream_t>(stream));
     return check_launch("pq_gemm_s8s8s32");
 }
@@ -252,7 +281,7 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
 // split-K plan: how many K-slices (1 = none) and which tile height.  Only when the tile grid fills at most half of the
 // 256 CUs even with 128-row tiles, K is long enough to amortise the extra pass, and the slices stay multiples of 128.
 static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
-    if (getenv("PQ_NO_SPLITK")) return 1;
+    if (options().no_splitk) return 1;
     if (M <= 64 || N < 1 || K < 2048) return 1;    // (M <= 64: the skinny kernel splits K inside the workgroup)
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
     const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
@@ -274,15 +303,9 @@ size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(int32_t) : 0;
 }
 
-int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
-                      const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M,
-                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
-    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: unknown dtype %d", out_dtype);
-    if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(y, M, N, ldy) ||
-        (M > 0 && !a_scale) || (N > 0 && !b_scale))
-        return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldy=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldy);
-    if (M == 0 || N == 0) return PQ_OK;
-    pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy};
+// the GEMM + epilogue of one (M x N x K, A rows x B rows) problem whose EpiArgs are already in the kernel's orientation
+static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
+                            int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.
@@ -290,8 +313,8 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
     const int ks = (v == V_SP256_16 || v == V_SP128_16 || v == V_RING128) && forced_variant() == V_AUTO ? splitk_plan(M, N, K, &tm) : 1;
     if (ks > 1 && workspace != nullptr) {
         const size_t need = (size_t)ks * (size_t)M * (size_t)N * sizeof(int32_t);
-        if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8: workspace %zu < %zu bytes", workspace_bytes, need);
-        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "pq_qlinear_s8: workspace must be 16-byte aligned");
+        if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "%s: workspace must be 16-byte aligned", what);
         int32_t* slabs = static_cast<int32_t*>(workspace);
         if (tm == 128) pq::launch_gemm_splitk_i32<128>(a, lda, b, ldb, slabs, M, N, K, ks, st);
         else pq::launch_gemm_splitk_i32<256>(a, lda, b, ldb, slabs, M, N, K, ks, st);
@@ -300,14 +323,42 @@ int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const 
             case PQ_FP16: pq::launch_splitk_reduce<PQ_FP16>(slabs, ks, M, N, epi, st); break;
             default: pq::launch_splitk_reduce<PQ_F32>(slabs, ks, M, N, epi, st); break;
         }
-        return check_launch("pq_qlinear_s8 (split-K)");
+        return check_launch(what);
     }
     switch (out_dtype) {
         case PQ_BF16: run_gemm_auto<PQ_BF16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
         case PQ_FP16: run_gemm_auto<PQ_FP16>(v, a, lda, b, ldb, epi, M, N, K, st); break;
         default: run_gemm_auto<PQ_F32>(v, a, lda, b, ldb, epi, M, N, K, st); break;
     }
-    return check_launch("pq_qlinear_s8");
+    return check_launch(what);
+}
+
+int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
+                      const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M,
+                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: unknown dtype %d", out_dtype);
+    if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(y, M, N, ldy) ||
+        (M > 0 && !a_scale) || (N > 0 && !b_scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldy=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldy);
+    if (M == 0 || N == 0) return PQ_OK;
+    pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy, 0};
+    return qlinear_core("pq_qlinear_s8", a, lda, b, ldb, epi, out_dtype, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// y^T[N, M] of the same qlinear: the kernel's rows are the weight rows (n), its columns the tokens (m); the epilogue applies
+// the token (column) scale first and runs the bias along rows, so every value has the bits of pq_qlinear_s8's y[m][n].
+size_t pq_qlinear_t_workspace_bytes(int64_t M, int64_t N, int64_t K) { return pq_qlinear_workspace_bytes(N, M, K); }
+
+int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
+                        const float* b_scale, const void* bias, void* yt, int64_t ldyt, int32_t out_dtype, int64_t M,
+                        int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_t: unknown dtype %d", out_dtype);
+    if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(yt, N, M, ldyt) ||
+        (M > 0 && !a_scale) || (N > 0 && !b_scale))
+        return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_t: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldyt=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldyt);
+    if (M == 0 || N == 0) return PQ_OK;
+    pq::EpiArgs epi{b_scale, a_scale, bias, yt, ldyt, pq::EPI_COL_FIRST | (bias ? pq::EPI_BIAS_ROWS : 0)};
+    return qlinear_core("pq_qlinear_s8_t", b, ldb, a, lda, epi, out_dtype, N, M, K, workspace, workspace_bytes, stream);
 }
 
 // ---- one-call dynamic qlinear: K1 (x -> xq, xs in the workspace) then pq_qlinear_s8 (with split-K slabs if planned).
@@ -355,7 +406,6 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
             const int axis = forced_variant() == V_AUTO ? tail_split_plan(M, N, &lead) : 0;
             return axis == 1 ? "sp256_16x16x64 + sp128 tail (N)" : axis == 2 ? "sp256_16x16x64 + sp128 tail (M)" : "sp256_16x16x64";
         }
-        case V_SP256_32: return "sp256_32x32x32";
         case V_SP128_16: return "sp128x256_16x16x64";
         case V_SP128X128: return "sp128x128_16x16x64";
         case V_RING128: return "ring128_16x16x64";

@@ -17,6 +17,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """-m gpu tests need a real MI355X: skip them (instead of failing) where there is none."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a GPU (MI355X): run with -m gpu on the GPU box")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture
+def pq_opt():
+    """Set behaviour switches of libpq_hip.so for one test (pq_set_option; the environment is only read once) and
+    restore the defaults afterwards."""
+    from protoquant_amd import _lib
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _lib.set_option(name, value)
+    yield set_
+    for n in touched:
+        _lib.set_option(n, "")
+
+
 def load_golden(path):
     z = np.load(path)
     d = {k: z[k] for k in z.files}

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import protoquant_amd as pq
+from protoquant_amd import _lib as _pqlib  # noqa: E402
 from oracle import c_oracle as C, qspec_numpy as Q
 from tests.gpu_util import TD, bits, to_gpu
 
@@ -76,11 +77,11 @@ def run(budget, seed):
       bv = Q.from_f32(rng.standard_normal(N2).astype(np.float32), code) if rng.random() < 0.5 else None
       want = Q.epilogue(acc, xs2, ws2, bv, code)
       for v in ("", "generic", "ring128", "sp256_16"):
-          os.environ["PQ_FORCE_VARIANT"] = v
+          _pqlib.set_option("PQ_FORCE_VARIANT", v)
           got = pq.qlinear_s8(torch.from_numpy(a).cuda(), torch.from_numpy(xs2).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws2).cuda(),
                               to_gpu(bv, code) if bv is not None else None, TD[code])
           bad += eqb(got, want, f"epilogue[{v or 'auto'}]", f"code={code} M={M2} N={N2} K={K2} bias={bv is not None}")
-      os.environ.pop("PQ_FORCE_VARIANT", None)
+      _pqlib.set_option("PQ_FORCE_VARIANT", "")
       n += 1
   print(f"fuzz_quant: {n} problems in {time.time() - t0:.0f} s, mismatches: {bad}")
   return n, bad

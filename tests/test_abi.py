@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 4 * 1024 * 1024 * 4      # quarter-filled grid, long K: split-K x4
     assert L.pq_gemm_variant_name(4096, 1024, 8192, 8192, 8192) == b"ring128_16x16x64"
     assert L.pq_gemm_variant_name(16, 4096, 4096, 4096, 4096) == b"skinny_16x16x64"               # decode-like: weight streaming
-    assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) in (b"sp256_16x16x64", b"sp256_32x32x32")
+    assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) == b"sp256_16x16x64"
     assert L.pq_gemm_variant_name(2048, 4096, 11008, 11008, 11008) == b"sp128x256_16x16x64"      # half a round of 256-row tiles
     assert L.pq_gemm_variant_name(5, 7, 3, 3, 3) == b"generic64"
 

@@ -1,0 +1,118 @@
+"""-m gpu: parity at the REAL shapes of BASELINE.json configs[3] (Llama-3-8B prefill, seq 4096) and configs[4]
+(Llama-3-70B column shards, 8 GPUs): the shapes where the dispatch changes (tail split, ring tiles, split-K on/off).
+
+Per shape (sampled-row pattern of test_full_size_cfg2_properties):
+  * K1: xq / xs of ALL 4096 token rows bit-exact vs the C oracle;
+  * K3: the int32 accumulator of 64 sampled rows x ALL N columns == torch._int_mm on the host (the primitive the contract
+    names) — and == an int64 matmul on a column sample; the full column checksum sum_m acc[m, :] == (sum_m xq[m, :]) . wq^T;
+  * K4: y of those rows bit-identical to the QSPEC epilogue (numpy oracle), with a bias on one shape per config;
+  * the variant string the library reports for the shape.
+Weights are synthetic int8 codes (gaussian, sigma 28, generated on the GPU and copied to the host for the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import qspec_numpy as Q
+from tests.gpu_util import bits, same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pq():
+    import protoquant_amd
+    from protoquant_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return protoquant_amd
+
+
+_X = {}
+
+
+def _activation(pq, K):
+    """x[4096, K] bf16 (seeded on the host), its GPU quantisation checked in full against the C oracle — once per K."""
+    if K not in _X:
+        g = torch.Generator().manual_seed(4242 + K)
+        x = torch.randn(4096, K, generator=g).to(torch.bfloat16)
+        q = pq.quantize(x.cuda())
+        xq, xs = C.quant_rowwise(bits(x), 0)
+        same(q.int_data, xq, f"xq K={K}"); same(q.scale, xs, f"xs K={K}")
+        _X.clear()                                   # keep one activation alive at a time
+        _X[K] = (q, xq, xs)
+    return _X[K]
+
+
+def _check(pq, M, N, K, want_variant, bias=False, nrows=64):
+    from protoquant_amd import _lib
+    q, xq, xs = _activation(pq, K)
+    gen = torch.Generator(device="cuda").manual_seed(N * 7 + K)
+    wq_t = (torch.randn(N, K, device="cuda", generator=gen) * 28).round().clamp(-127, 127).to(torch.int8)
+    ws_t = torch.rand(N, device="cuda", generator=gen) * 1e-2 + 1e-4
+    b_t = (torch.randn(N, device="cuda", generator=gen) * 0.05).to(torch.bfloat16) if bias else None
+    name = _lib.lib().pq_gemm_variant_name(M, N, K, K, K).decode()
+    assert want_variant in name, (name, want_variant)
+    y = pq.qlinear_s8(q.int_data, q.scale, wq_t, ws_t, b_t, torch.bfloat16)
+    acc = pq.int_mm(q.int_data, wq_t)
+    torch.cuda.synchronize()
+    wq = wq_t.cpu()
+    rows = np.sort(np.random.default_rng(N + K).choice(M, nrows, replace=False))
+    rt = torch.from_numpy(rows).cuda()
+    # a3: the contract's primitive on the host, all N columns of the sampled rows
+    acc_want = torch._int_mm(torch.from_numpy(np.ascontiguousarray(xq[rows])), wq.t()).numpy()
+    cols = np.random.default_rng(K).choice(N, min(N, 257), replace=False)
+    assert np.array_equal(acc_want[:, cols].astype(np.int64), xq[rows].astype(np.int64) @ wq.numpy()[cols].astype(np.int64).T)
+    same(acc[rt].contiguous(), acc_want, f"acc rows {M}x{N}x{K}")
+    # a4: QSPEC epilogue on those accumulators
+    y_want = Q.epilogue(acc_want, xs[rows], ws_t.cpu().numpy(), bits(b_t) if bias else None, 0)
+    same(y[rt].contiguous(), y_want, f"y rows {M}x{N}x{K}")
+    # checksum of checksums over ALL rows (exact in float64: every partial sum is an integer < 2^53)
+    colsum = acc.sum(dim=0, dtype=torch.int64).cpu().numpy()
+    want = (xq.astype(np.float64).sum(axis=0) @ wq.numpy().astype(np.float64).T).astype(np.int64)
+    assert np.array_equal(colsum, want), f"column checksum {M}x{N}x{K}"
+    return y, acc
+
+
+# BASELINE configs[3]: Llama-3-8B, bs 1, seq 4096 -> M = 4096
+@pytest.mark.parametrize("N,K,variant,bias", [
+    (6144, 4096, "sp256_16x16x64 + sp128 tail (N)", True),      # fused qkv: 384 tiles = 1.5 rounds -> tail split
+    (28672, 4096, "sp256_16x16x64", False),                     # fused gate+up: 1792 tiles = 7 full rounds
+    (4096, 14336, "sp256_16x16x64", False),                     # down: one round, K = 14336
+    (128256, 4096, "sp256_16x16x64 + sp128 tail (N)", False),   # lm_head: 8016 tiles + tail split
+    (1024, 4096, "ring128", False),                             # unfused k / v projection
+])
+def test_llama8b_prefill_shapes(pq, N, K, variant, bias):
+    _check(pq, 4096, N, K, variant, bias=bias)
+
+
+# BASELINE configs[4]: Llama-3-70B, W column-sharded over 8 GPUs: per-GPU shard shapes at M = 4096
+@pytest.mark.parametrize("N,K,variant,bias", [
+    (1024, 8192, "ring128", True),            # q / o shard
+    (3584, 8192, "sp256_16x16x64", False),    # gate / up shard
+    (1024, 28672, "ring128", False),          # down shard (column-sharded: full K)
+    (16032, 8192, "sp256_16x16x64", False),   # lm_head shard: 128256 / 8 = 16032 = 62.6 tile columns (ragged last tile)
+    (128, 8192, "", False),                   # k / v shard (8 KV heads x 128 / 8 GPUs)
+])
+def test_llama70b_shard_shapes(pq, N, K, variant, bias, pq_opt):
+    y, acc = _check(pq, 4096, N, K, variant, bias=bias)
+    # the same shard through the other split-K setting: bit-identical (qlinear_s8 hands the library the workspace it
+    # asks for; PQ_NO_SPLITK forces the single-pass kernels)
+    from protoquant_amd import _lib
+    used_splitk = _lib.lib().pq_qlinear_workspace_bytes(4096, N, K) > 0
+    pq_opt("PQ_NO_SPLITK", "1")
+    assert _lib.lib().pq_qlinear_workspace_bytes(4096, N, K) == 0
+    y2, _ = _check(pq, 4096, N, K, variant, bias=bias)
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), f"split-K {'on' if used_splitk else 'off'} vs forced off"
+
+
+def test_70b_shard_splitk_forced_on_matches(pq, pq_opt):
+    """The slab path at a 70B shard shape where the planner would not pick it by itself: 4096 x 512 x 8192 (a quarter-filled
+    grid, K >= 8192 -> 4 slices) against the single-pass result, bit for bit, plus the oracle on sampled rows."""
+    from protoquant_amd import _lib
+    M, N, K = 4096, 512, 8192
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0
+    y, _ = _check(pq, M, N, K, "")
+    pq_opt("PQ_NO_SPLITK", "1")
+    y2, _ = _check(pq, M, N, K, "")
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))

@@ -37,10 +37,10 @@ def test_golden_quantize(pq, golden):
     same(pq.dequantize(qc), g["x_coldeq"], "x_coldeq")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128"])
-def test_golden_gemm_and_qlinear(pq, golden, variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+def test_golden_gemm_and_qlinear(pq, golden, variant, pq_opt):
     g = golden
-    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     xq = torch.from_numpy(g["xq"]).cuda(); wq = torch.from_numpy(g["wq"]).cuda()
     xs = torch.from_numpy(g["xs"]).cuda(); ws = torch.from_numpy(g["ws"]).cuda()
     same(pq.int_mm(xq, wq), g["acc"], "acc")
@@ -70,10 +70,10 @@ SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), 
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128"])
-def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+def test_int_gemm_exact_full_range(pq, M, N, K, variant, pq_opt):
     """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
-    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M * 1000003 + N * 1009 + K)
     a = rng.integers(-128, 128, (M, K), dtype=np.int8)
     b = rng.integers(-128, 128, (N, K), dtype=np.int8)
@@ -82,10 +82,10 @@ def test_int_gemm_exact_full_range(pq, M, N, K, variant, monkeypatch):
     same(got, want, f"acc {M}x{N}x{K} {variant}")
 
 
-@pytest.mark.parametrize("variant", ["sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128", "generic"])
-def test_gemm_identity_asymmetric(pq, variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["sp256_16", "sp128_16", "sp128x128", "ring128", "generic"])
+def test_gemm_identity_asymmetric(pq, variant, pq_opt):
     """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
-    monkeypatch.setenv("PQ_FORCE_VARIANT", variant)
+    pq_opt("PQ_FORCE_VARIANT", variant)
     n = 256
     a = np.eye(n, dtype=np.int8)
     b = (np.arange(n * n, dtype=np.int64).reshape(n, n) % 251 - 125).astype(np.int8)
@@ -166,9 +166,9 @@ def test_quant_strided_and_unaligned(pq):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
                                               (512, 1024, 512, 0, False)])
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_32", "sp128_16", "sp128x128", "ring128"])
-def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, monkeypatch):
-    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, pq_opt):
+    pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M + N + K + code)
     x = Q.from_f32(rng.standard_normal((M, K)).astype(np.float32), code)
     w = Q.from_f32((rng.standard_normal((N, K)) * 0.02).astype(np.float32), code)
@@ -204,7 +204,7 @@ def test_qlinear_unaligned_scales_and_output(pq):
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 260, 8192, 0, True), (512, 1024, 8192, 0, False), (130, 517, 8192, 2, True),
                                               (1024, 1024, 8192, 1, True), (2048, 1024, 8192, 0, False), (1500, 1000, 16384, 0, True), (128, 1024, 16384, 0, True),
                                               (200, 2048, 14336, 1, False)])
-def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
+def test_splitk_bit_identical(pq, M, N, K, code, bias, pq_opt):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
     == the single-pass kernel (PQ_NO_SPLITK)."""
     from protoquant_amd import _lib
@@ -218,7 +218,7 @@ def test_splitk_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
             to_gpu(bv, code) if bias else None, TD[code])
     same(pq.qlinear_s8(*args), want, "split-K y")
-    monkeypatch.setenv("PQ_NO_SPLITK", "1")
+    pq_opt("PQ_NO_SPLITK", "1")
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0
     same(pq.qlinear_s8(*args), want, "single-pass y")
 
@@ -268,10 +268,10 @@ def test_skinny_strided_operands_and_qlinear_module(pq):
 
 
 @pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "skinny"])
-def test_extreme_accumulation_near_int32_limit(pq, variant, monkeypatch):
+def test_extreme_accumulation_near_int32_limit(pq, variant, pq_opt):
     """K = 130944 with every code at -128 on both sides: |acc| = 128^2 * K = 2 145 386 496, 2.1 M short of 2^31 — the
     accumulators must neither saturate nor wrap, in any variant (skinny: M = 16; the others: M = 192)."""
-    monkeypatch.setenv("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
+    pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     K, N = 130944, 320
     for M in ((16,) if variant == "skinny" else (192,)):
         a = torch.full((M, K), -128, dtype=torch.int8, device="cuda"); b = torch.full((N, K), -128, dtype=torch.int8, device="cuda")
@@ -283,7 +283,7 @@ def test_extreme_accumulation_near_int32_limit(pq, variant, monkeypatch):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(2048, 11008, 128, 0, True), (4096, 4352, 128, 1, False), (11008, 2048, 128, 0, True),
                                               (2050, 10990, 256, 2, True)])
-def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
+def test_tail_split_bit_identical(pq, M, N, K, code, bias, pq_opt):
     """Grids a little over a whole number of rounds: the trailing tile columns/rows run as a second launch of 128-row
     tiles.  Result == the oracle, == the single launch (PQ_NO_TAILSPLIT), and the int32 twin stays exact."""
     from protoquant_amd import _lib
@@ -298,7 +298,7 @@ def test_tail_split_bit_identical(pq, M, N, K, code, bias, monkeypatch):
     args = (ta, torch.from_numpy(xs).cuda(), tb, torch.from_numpy(ws).cuda(), to_gpu(bv, code) if bias else None, TD[code])
     same(pq.qlinear_s8(*args), want, "tail-split y")
     same(pq.int_mm(ta, tb), acc, "tail-split acc")
-    monkeypatch.setenv("PQ_NO_TAILSPLIT", "1")
+    pq_opt("PQ_NO_TAILSPLIT", "1")
     assert b"tail" not in _lib.lib().pq_gemm_variant_name(M, N, K, K, K)
     same(pq.qlinear_s8(*args), want, "single-launch y")
 

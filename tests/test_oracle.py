@@ -242,3 +242,84 @@ def test_rms_sumsq_order_is_the_documented_one():
     rs_want = np.float32(1) / np.sqrt(np.float32(want / np.float32(3000)))
     assert rs_c[0].view(np.uint32) == np.float32(rs_want).view(np.uint32)
     assert abs(float(got) - float((x.astype(np.float64) ** 2).sum())) <= 1e-6 * float(got)
+
+
+# ---------------------------------------------------------------- the fixtures still are what torch._int_mm + QSPEC produce
+def test_golden_regenerates_from_torch_ref(golden):
+    """Re-runs oracle/torch_ref.py (QSPEC float stages in plain torch around torch._int_mm — the primitive BASELINE.json
+    names) on every fixture's STORED inputs and compares every stored output, bit for bit: the committed files cannot
+    drift away from the generator, and the int32 accumulator is pinned to torch._int_mm run here."""
+    import torch
+    from oracle import torch_ref as R
+    g = golden
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[g["dtype"]]
+
+    def t(a):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a) if g["code"] == 2 else torch.from_numpy(a.view(np.int16)).view(td)
+
+    def b(x):
+        x = x.contiguous()
+        return x.numpy() if x.dtype in (torch.float32, torch.int8, torch.int32) else x.view(torch.int16).numpy().view(np.uint16)
+
+    x, w = t(g["x"]), t(g["w"])
+    bias = t(g["bias"]) if g["bias"] is not None else None
+    wq, ws = R.quantize_ref(w, 1)
+    eq(b(wq), g["wq"]); eq(b(ws), g["ws"])
+    y, xq, xs, acc = R.qlinear_ref(x, wq, ws, bias)
+    eq(b(xq), g["xq"]); eq(b(xs), g["xs"]); eq(b(acc), g["acc"]); eq(b(y), g["y"])
+    assert torch.equal(acc, torch._int_mm(xq, wq.t()))                      # a3: the contract primitive itself
+    cq, cs = R.quantize_ref(x, 0)
+    eq(b(cq), g["x_colq"]); eq(b(cs), g["x_cols"])
+    eq(b(R.dequantize_ref(xq, xs, 1, td)), g["x_deq"]); eq(b(R.dequantize_ref(cq, cs, 0, td)), g["x_coldeq"])
+
+
+def test_c_oracle_under_asan_ubsan(tmp_path):
+    """the plain-C restatement built with -fsanitize=address,undefined (host only — GPU sanitizers are not
+    available on this pool) reproduces a golden fixture with no sanitizer report.  Runs in a child process: the sanitizer
+    runtime must be the first library loaded."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_asan.so")
+    r = subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-std=gnu11", "-o", so,
+                        os.path.join(root, "oracle", "qspec_oracle.c"), "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    fixtures = sorted(glob.glob(os.path.join(root, "tests", "golden", "*.npz")))
+    prods = sorted(glob.glob(os.path.join(root, "tests", "golden", "producer", "*.npz")))
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from oracle import c_oracle as C
+import ctypes
+C._lib = ctypes.CDLL({so!r})
+for p in {fixtures!r}:
+    z = np.load(p); code = {{"bf16": 0, "fp16": 1, "f32": 2}}[str(z["dtype"])]
+    xq, xs = C.quant_rowwise(z["x"], code); wq, ws = C.quant_rowwise(z["w"], code)
+    assert np.array_equal(xq, z["xq"]) and np.array_equal(wq, z["wq"])
+    cq, cs = C.quant_colwise(z["x"], code); assert np.array_equal(cq, z["x_colq"])
+    assert np.array_equal(C.gemm_s8s8s32(xq, wq), z["acc"])
+    bias = z["bias"] if "bias" in z.files else None
+    assert np.array_equal(C.qlinear_s8(xq, xs, wq, ws, bias, code), z["y"])
+    C.dequant(xq, xs, 1, code)
+for p in {prods!r}:
+    z = np.load(p); code = int(z["code"])
+    if "g" in z.files:
+        q = C.silu_mul_quant_rowwise(z["g"], z["u"], code)[0]; assert np.array_equal(q, z["q"])
+    else:
+        q = C.rmsnorm_quant_rowwise(z["x"], z["w"], float(z["eps"]), code)[0]; assert np.array_equal(q, z["q"])
+print("ASAN_OK")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ASAN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]

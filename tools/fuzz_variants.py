@@ -4,8 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import protoquant_amd as pq
+from protoquant_amd import _lib as _pqlib  # noqa: E402
 
-VARIANTS = ["", "sp256_16", "sp256_32", "sp128_16", "sp128x128", "ring128", "skinny"]
+VARIANTS = ["", "sp256_16", "sp128_16", "sp128x128", "ring128", "skinny"]
 DT = [torch.bfloat16, torch.float16, torch.float32]
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 budget = float(os.environ.get("FUZZ_SECONDS", "120"))
@@ -23,12 +24,12 @@ while time.time() - t0 < budget:
     xs = torch.rand(M, device="cuda") + 0.01; ws = torch.rand(N, device="cuda") * 0.01 + 1e-4
     dt = DT[int(rng.integers(0, 3))]
     bias = torch.randn(N, device="cuda").to(dt) if rng.random() < 0.5 else None
-    os.environ["PQ_FORCE_VARIANT"] = "generic"
+    _pqlib.set_option("PQ_FORCE_VARIANT", "generic")
     ref_y = pq.qlinear_s8(a, xs, b, ws, bias, dt).clone(); ref_acc = pq.int_mm(a, b).clone()
     pad_y, off_y = int(rng.choice([0, 0, 8, 24, 3])), int(rng.choice([0, 0, 8, 1]))
     ybig = torch.full((M, N + pad_y + off_y), 7.0, dtype=dt, device="cuda")
     for v in VARIANTS:
-        os.environ["PQ_FORCE_VARIANT"] = v
+        _pqlib.set_option("PQ_FORCE_VARIANT", v)
         yv = ybig[:, off_y:off_y + N]                  # the output as a window of a wider matrix: ld > N, maybe unaligned
         pq.qlinear_s8(a, xs, b, ws, bias, dt, out=yv)
         y = yv.contiguous(); acc = pq.int_mm(a, b)
@@ -42,6 +43,6 @@ while time.time() - t0 < budget:
             bad += 1
             print(f"MISMATCH variant={v or 'auto'} M={M} N={N} K={K} pads=({pad_a},{pad_b}) dtype={dt} bias={bias is not None}: {d} elements")
     n += 1
-os.environ.pop("PQ_FORCE_VARIANT", None)
+_pqlib.set_option("PQ_FORCE_VARIANT", "")
 print(f"fuzz: {n} problems x {len(VARIANTS)} variants in {time.time() - t0:.0f} s, mismatching runs: {bad}")
 print("FUZZ", "CLEAN" if bad == 0 else "FAILED")

@@ -28,7 +28,7 @@ for M, N, K, name in SHAPES:
     ops = 2.0 * M * N * K
     row = f"{name:18s} {M:5d} x {N:5d} x {K:5d} "
     for v in ("sp128_16", "sp128x128", "ring128", ""):
-        os.environ["PQ_FORCE_VARIANT"] = v
+        L.set_option("PQ_FORCE_VARIANT", v)
         wb = lib.pq_qlinear_workspace_bytes(M, N, K) if v == "" else 0
         wsp = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
         f = lambda: lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K, wsp.data_ptr() if wb else None, wb, st)

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import protoquant_amd as pq  # noqa: E402
+from protoquant_amd import _lib as _pqlib  # noqa: E402
 
 
 def timeit(fn, iters=50, warm=10):
@@ -42,11 +43,11 @@ def main():
     med, mn = timeit(lambda: pq.dequantize(qx))
     print(f"dequant {M}x{K}->bf16: median {med:.1f} us -> {(M * K * 3 + 4 * M) / med / 1e6:.2f} TB/s")
     ops = 2.0 * M * N * K
-    os.environ["PQ_FORCE_VARIANT"] = "generic"
+    _pqlib.set_option("PQ_FORCE_VARIANT", "generic")
     ref_acc = pq.int_mm(qx.int_data, qw.int_data)
     ref_y = pq.qlinear_s8(qx.int_data, qx.scale, qw.int_data, qw.scale, None, torch.bfloat16)
-    for v in ("generic", "sp256_16", "sp256_32"):
-        os.environ["PQ_FORCE_VARIANT"] = v
+    for v in ("generic", "sp256_16"):
+        _pqlib.set_option("PQ_FORCE_VARIANT", v)
         acc = pq.int_mm(qx.int_data, qw.int_data)
         y = pq.qlinear_s8(qx.int_data, qx.scale, qw.int_data, qw.scale, None, torch.bfloat16)
         ok = torch.equal(acc, ref_acc) and torch.equal(y.view(torch.int16), ref_y.view(torch.int16))
@@ -57,7 +58,7 @@ def main():
               f"({ops / med / 1e6 / 5033 * 100:.1f}% of 5033) min-> {ops / mn / 1e6:.1f}")
         med, mn = timeit(lambda: pq.int_mm(qx.int_data, qw.int_data), iters=20 if v == "generic" else 50)
         print(f"GEMM s32 {v:9s}: median {med:.1f} us -> {ops / med / 1e6:.1f} TOPS")
-    os.environ["PQ_FORCE_VARIANT"] = ""
+    _pqlib.set_option("PQ_FORCE_VARIANT", "")
     lin = pq.qlinear.from_qtensor(qw)
     med, mn = timeit(lambda: lin(x))
     print(f"qlinear fwd (K1+K3/K4 via python): median {med:.1f} us -> {ops / med / 1e6:.1f} TOPS")
