@@ -443,7 +443,7 @@ def main():
     if tp:
         fence()
     consistent = (t_gemm + t_k1) <= 1.05 * t_stepc
-    assert consistent or args.no_consistency_check, \
+    assert consistent or args.no_consistency_check or args.share_gpu, \
         f"inconsistent timings: GEMM {t_gemm:.2f} us + K1 {t_k1:.2f} us > 1.05 x compute step {t_stepc:.2f} us"
 
     ops_job = 2.0 * M * N * K * (1 if tp else world)       # whole job per step

@@ -63,6 +63,11 @@ int32_t pq_comm_count(void* comm, int32_t* nranks);
 int32_t pq_unstack_cols(const void* stacked, void* y_full, int32_t nranks, int64_t M, int64_t n_shard, int32_t dtype,
                         void* stream);
 
+/* the ragged layout kernel alone: stacked[nranks, M, ceil(n_total / nranks)] (rank r's block holds its shard_bounds() width,
+ * the rest is padding) -> y_full[M, n_total] with leading dimension ld_full; exposed for tests */
+int32_t pq_unstack_cols_v(const void* stacked, void* y_full, int64_t ld_full, int32_t nranks, int64_t M, int64_t n_total,
+                          int32_t dtype, void* stream);
+
 /* Row-sharded (K-split) qlinear, the Megatron pairing of a column-sharded producer: every rank holds
  * partial[nranks * m_shard, N] in f32 — its K-slice's contribution to the whole output — and receives the SUM over ranks of
  * row block `rank`: y_rows[m_shard, N], cast (RNE) to out_dtype.  One ncclReduceScatter (f32, sum) — row blocks are

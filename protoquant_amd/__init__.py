@@ -2,10 +2,10 @@
 (QTensor, quantize(), dequantize(), qlinear).  Hot path = hand-written HIP (gfx950) in
 libpq_hip.so reached through the C-ABI in include/pq_hip.h; there is no CPU/eager fallback."""
 from .qtensor import QTensor, quantize, dequantize, silu_mul_quantize, rmsnorm_quantize
-from .qlinear import qlinear, qlinear_s8, qlinear_dyn, int_mm, swap_linears, FusedQLinear, GatedMLP
+from .qlinear import qlinear, qlinear_s8, qlinear_s8_t, qlinear_dyn, int_mm, clear_workspaces, swap_linears, FusedQLinear, GatedMLP
 from .sharded import (ColumnShardedQLinear, RcclColumnGather, RcclRowReduceScatter, RowShardedQLinear, ShardedGatedMLP,
-                      gather_columns, gather_columns_overlapped, reduce_rows, shard_bounds)
+                      gather_columns, gather_columns_overlapped, gather_rows_t, reduce_rows, shard_bounds)
 
 __all__ = ["QTensor", "quantize", "dequantize", "qlinear", "qlinear_s8", "qlinear_dyn", "int_mm", "swap_linears", "FusedQLinear", "GatedMLP", "silu_mul_quantize", "rmsnorm_quantize",
            "ColumnShardedQLinear", "RcclColumnGather", "gather_columns", "shard_bounds", "RowShardedQLinear", "ShardedGatedMLP",
-           "RcclRowReduceScatter", "reduce_rows", "gather_columns_overlapped"]
+           "RcclRowReduceScatter", "reduce_rows", "gather_columns_overlapped", "gather_rows_t", "qlinear_s8_t", "clear_workspaces"]

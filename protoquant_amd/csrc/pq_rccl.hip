@@ -208,6 +208,19 @@ int32_t pq_unstack_cols(const void* stacked, void* y_full, int32_t nranks, int64
     return launch_unstack(stacked, y_full, nranks, M, n_shard, dtype, static_cast<hipStream_t>(stream));
 }
 
+int32_t pq_unstack_cols_v(const void* stacked, void* y_full, int64_t ld_full, int32_t nranks, int64_t M, int64_t n_total, int32_t dtype, void* stream) {
+    if (nranks < 1 || M < 0 || n_total < 0 || dtype < 0 || dtype > 2 || ld_full < n_total || ((M > 0 && n_total > 0) && (!stacked || !y_full)))
+        return fail(1, "pq_unstack_cols_v: bad arguments");
+    if (M == 0 || n_total == 0) return 0;
+    const int unit = elem_bytes(dtype) / 2;
+    const int64_t n_max = (n_total + nranks - 1) / nranks;
+    unstack_ragged_kernel<<<dim3((unsigned)grid_for((int64_t)nranks * M * n_max * unit)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const unsigned short*>(stacked), static_cast<unsigned short*>(y_full), nranks, M, n_total * unit, n_max * unit, ld_full * unit, unit);
+    int32_t rc = 0;
+    launch_ok("unstack launch", &rc);
+    return rc;
+}
+
 int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void* y_full, int64_t M, int64_t n_shard,
                           int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!comm || nranks < 1 || M < 0 || n_shard < 0 || dtype < 0 || dtype > 2) return fail(1, "pq_allgather_cols: bad arguments");

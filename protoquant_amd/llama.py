@@ -1,0 +1,89 @@
+"""Call-site integration for Llama-family decoder layers (transformers' LlamaDecoderLayer shape: input_layernorm -> self_attn with
+q_proj / k_proj / v_proj / o_proj -> post_attention_layernorm -> mlp), SURVEY.md §8(f)1-2 applied to a whole model:
+
+* both RMSNorms of a layer are fused into the activation quantisation of the projections they feed (``rmsnorm_quantize``: the
+  normalised activation never reaches HBM, the norm costs no traffic beyond the quantisation that had to happen anyway);
+* q / k / v share that one quantisation and ONE GEMM launch (``FusedQLinear``, N = hidden + 2 * kv);
+* gate / up / down are a ``GatedMLP`` (fused gate+up GEMM, silu*mul fused into the quantisation of down's input).
+
+The stock attention code keeps calling ``self.q_proj(h)``, ``self.k_proj(h)``, ``self.v_proj(h)``: ``h`` is now a per-token
+``QTensor`` (it only needs ``.shape`` besides being handed to the projections), the first call runs the fused GEMM and the other
+two return their column slices of its output.  Attention itself (rope, SDPA), the residual adds, the final norm and the embedding
+stay stock torch-ROCm ops.  ``swap_linears(model, fuse_gated_mlp=True)`` must have run first."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .qlinear import FusedQLinear, GatedMLP, qlinear
+from .qtensor import QTensor, rmsnorm_quantize
+
+
+class RMSNormQuant(nn.Module):
+    """RMSNorm whose output is the per-token int8 quantisation of the normalised activation (QSPEC N1-N6 then Q1-Q6)."""
+
+    def __init__(self, weight: torch.Tensor, eps: float):
+        super().__init__()
+        self.weight = nn.Parameter(weight.detach().clone(), requires_grad=False)
+        self.variance_epsilon = float(eps)
+
+    def forward(self, x: torch.Tensor) -> QTensor:
+        return rmsnorm_quantize(x, self.weight, self.variance_epsilon)
+
+    def extra_repr(self):
+        return f"{tuple(self.weight.shape)}, eps={self.variance_epsilon} -> int8 per-token QTensor"
+
+
+class _FusedSlice(nn.Module):
+    """Projection number `index` of a FusedQLinear shared by sibling slices: the slice that sees a new input runs the fused
+    GEMM; its siblings, called with the SAME input object right after (as the attention code does), take their part of it."""
+
+    def __init__(self, shared: "_SharedFused", index: int):
+        super().__init__()
+        self._shared = [shared]            # (a list: the shared module is registered once, on its owner)
+        self.index = index
+
+    def forward(self, x):
+        return self._shared[0].part(x, self.index)
+
+
+class _SharedFused(nn.Module):
+    def __init__(self, fused: FusedQLinear):
+        super().__init__()
+        self.fused = fused
+        self._key, self._outs, self._left = None, None, 0
+
+    def part(self, x, index):
+        if self._outs is None or self._key is not x:
+            self._key, self._outs, self._left = x, self.fused(x), len(self.fused.splits)
+        out = self._outs[index]
+        self._left -= 1
+        if self._left == 0:                 # every sibling served: drop the references
+            self._key, self._outs = None, None
+        return out
+
+
+def _is_rmsnorm(m) -> bool:
+    return hasattr(m, "weight") and hasattr(m, "variance_epsilon") and isinstance(getattr(m, "weight"), torch.Tensor) and m.weight.dim() == 1
+
+
+def fuse_llama_layers(model: nn.Module, fuse_norms: bool = True, fuse_qkv: bool = True) -> int:
+    """Apply the fusions above to every decoder layer found in `model` (in place); returns the number of layers changed."""
+    n = 0
+    for layer in model.modules():
+        attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+        if attn is None or mlp is None or not hasattr(layer, "input_layernorm") or not hasattr(layer, "post_attention_layernorm"):
+            continue
+        q, k, v = (getattr(attn, p, None) for p in ("q_proj", "k_proj", "v_proj"))
+        if not all(isinstance(p, qlinear) for p in (q, k, v)):
+            continue
+        if fuse_qkv:
+            attn.qkv_fused = _SharedFused(FusedQLinear([q, k, v]))
+            attn.q_proj, attn.k_proj, attn.v_proj = (_FusedSlice(attn.qkv_fused, i) for i in range(3))
+        if fuse_norms and _is_rmsnorm(layer.input_layernorm):
+            layer.input_layernorm = RMSNormQuant(layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
+        mlp_ok = isinstance(mlp, GatedMLP) or all(isinstance(getattr(mlp, p, None), qlinear) for p in ("gate_proj", "up_proj"))
+        if fuse_norms and _is_rmsnorm(layer.post_attention_layernorm) and mlp_ok:
+            layer.post_attention_layernorm = RMSNormQuant(layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
+        n += 1
+    return n

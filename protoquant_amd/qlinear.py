@@ -29,20 +29,43 @@ def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
 
 
 _WORKSPACES: dict = {}
-_RETIRED: list = []
+_RETIRED: list = []        # buffers outgrown WHILE a hipGraph was being captured (the graph holds their address)
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Caller-owned scratch (split-K slabs, the one-call path's codes and scales): one growing buffer per (device, stream) —
-    reuse is ordered by the stream, and two streams never share a buffer."""
+    """Caller-owned scratch (split-K slabs, the one-call path's codes and scales): one buffer per (device, stream) — reuse is
+    ordered by the stream, and two streams never share a buffer.  It grows geometrically (at least 2x), so a run with rising M
+    reallocates O(log) times; an outgrown buffer is simply dropped — the caching allocator hands its memory out again in stream
+    order, which is safe because every use of it was enqueued on this stream before the free — unless a hipGraph capture is
+    in progress: a captured launch keeps the raw address, so that buffer is parked instead (clear_workspaces() releases all)."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _RETIRED.append(buf)      # a captured hipGraph may still hold its address: never free a workspace
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if buf is not None and capturing:
+            _RETIRED.append(buf)
+        size = nbytes if buf is None else max(nbytes, 2 * buf.numel())
+        buf = torch.empty((size,), dtype=torch.uint8, device=device)
         _WORKSPACES[key] = buf
+        if capturing:
+            _RETIRED.append(buf)      # keep it alive as long as graphs may replay, even if a later call outgrows it
     return buf
+
+
+def clear_workspaces() -> None:
+    """Drop every cached workspace (call when no captured hipGraph that used this module will be replayed again)."""
+    _WORKSPACES.clear()
+    _RETIRED.clear()
+
+
+def _check_operand(t, name: str, dev, dtype, numel=None):
+    """The C-ABI takes raw pointers: a CPU tensor, a wrong dtype or a strided vector would be read as garbage (or fault)."""
+    if t.device != dev:
+        raise L.PQError(f"{name} is on {t.device}, expected {dev}: protoquant_amd has no CPU fallback — move the module / tensor to the GPU")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if numel is not None and (t.dim() != 1 or t.numel() != numel or (numel > 1 and t.stride(0) != 1)):
+        raise ValueError(f"{name} must be a contiguous vector of {numel} elements, got shape {tuple(t.shape)} stride {t.stride()}")
 
 
 def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
@@ -57,6 +80,15 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
     code = L.dtype_code(out_dtype)
     if bias is not None and bias.dtype != out_dtype:
         bias = bias.to(out_dtype)
+    dev = xq.device
+    _check_operand(xq, "xq", dev, torch.int8); _check_operand(wq, "wq", dev, torch.int8)
+    _check_operand(xs, "xs", dev, torch.float32, M); _check_operand(ws, "ws", dev, torch.float32, N)
+    if bias is not None:
+        _check_operand(bias, "bias", dev, out_dtype, N)
+    if out is not None:
+        _check_operand(out, "out", dev, out_dtype)
+        if out.dim() != 2 or out.shape != (M, N) or (N > 1 and out.stride(1) != 1):
+            raise ValueError(f"out must be a row-major [{M}, {N}] tensor, got {tuple(out.shape)} stride {out.stride()}")
     y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=xq.device)
     wbytes = L.lib().pq_qlinear_workspace_bytes(M, N, K)        # > 0: split-K pays for this shape
     wsp = _workspace(xq.device, wbytes) if wbytes else None
@@ -66,6 +98,36 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
                                       M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes,
                                       L.stream_ptr(xq)), "qlinear_s8")
     return y
+
+
+def qlinear_s8_t(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """The same fused GEMM + epilogue with the output TRANSPOSED: returns yt[N, M], yt[n][m] bit-identical to
+    qlinear_s8(...)[m][n] (C-ABI pq_qlinear_s8_t).  The column-sharded configuration gathers these row blocks contiguously."""
+    L.require_gpu(xq, "qlinear_s8_t(xq)")
+    xq, wq = L.row_major_2d(xq), L.row_major_2d(wq)
+    M, K = xq.shape
+    N = wq.shape[0]
+    if wq.shape[1] != K:
+        raise ValueError(f"shape mismatch: x has K={K}, weight has K={wq.shape[1]}")
+    code = L.dtype_code(out_dtype)
+    if bias is not None and bias.dtype != out_dtype:
+        bias = bias.to(out_dtype)
+    dev = xq.device
+    _check_operand(xq, "xq", dev, torch.int8); _check_operand(wq, "wq", dev, torch.int8)
+    _check_operand(xs, "xs", dev, torch.float32, M); _check_operand(ws, "ws", dev, torch.float32, N)
+    if bias is not None:
+        _check_operand(bias, "bias", dev, out_dtype, N)
+    if out is not None and (out.device != dev or out.dtype != out_dtype or out.shape != (N, M) or (M > 1 and out.stride(1) != 1)):
+        raise ValueError(f"out must be a row-major [{N}, {M}] {out_dtype} tensor on {dev}")
+    yt = out if out is not None else torch.empty((N, M), dtype=out_dtype, device=dev)
+    wbytes = L.lib().pq_qlinear_t_workspace_bytes(M, N, K)
+    wsp = _workspace(dev, wbytes) if wbytes else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().pq_qlinear_s8_t(xq.data_ptr(), L.ld(xq), xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, yt.data_ptr(), L.ld(yt), code,
+                                        M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes, L.stream_ptr(xq)), "qlinear_s8_t")
+    return yt
 
 
 def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) -> torch.Tensor:
@@ -84,6 +146,9 @@ def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) 
         raise ValueError(f"shape mismatch: x has K={K}, weight has K={wq.shape[1]}")
     if bias is not None and bias.dtype != x.dtype:
         bias = bias.to(x.dtype)
+    _check_operand(wq, "wq", x.device, torch.int8); _check_operand(ws, "ws", x.device, torch.float32, N)
+    if bias is not None:
+        _check_operand(bias, "bias", x.device, x.dtype, N)
     y = torch.empty((lead, N), dtype=x.dtype, device=x.device)
     wbytes = L.lib().pq_qlinear_dyn_workspace_bytes(lead, N, K)
     wsp = _workspace(x.device, max(wbytes, 256))

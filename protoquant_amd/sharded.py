@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from .qlinear import FusedQLinear, qlinear, qlinear_s8
+from .qlinear import FusedQLinear, qlinear, qlinear_s8, qlinear_s8_t
 from .qtensor import QTensor, quantize, silu_mul_quantize
 
 
@@ -91,10 +91,12 @@ def gather_columns_overlapped(produce_rows, M: int, n_total: int, chunks: int, d
 
 
 class RcclColumnGather:
-    """The same exchange through the native C-ABI (include/pq_rccl.h): a dedicated RCCL communicator, one
-    ncclAllGather into a stacked workspace and the layout-fix kernel, all stream-ordered on torch's current
-    stream.  The 128-byte unique id is created on rank 0 and distributed with torch.distributed (any backend).
-    Requires equal shard widths (n_total % world == 0)."""
+    """The same exchange through the native C-ABI (include/pq_rccl.h): a dedicated RCCL communicator, ncclAllGather into a
+    stacked workspace and the layout kernel (pq_allgather_cols_v: equal OR ragged shards), all stream-ordered on torch's
+    current stream; a row-chunked overlapped form (pq_allgather_cols_rows_async + pq_comm_join: the exchange of a row block
+    runs on the communicator's side stream while the next block's GEMM runs on torch's stream — no allocation per chunk); and
+    the contiguous gather of TRANSPOSED shards (pq_allgather_rows_t: no staging, no layout kernel).
+    The 128-byte unique id is created on rank 0 and distributed with torch.distributed (any backend)."""
 
     def __init__(self, group=None):
         from . import _rccl
@@ -112,21 +114,75 @@ class RcclColumnGather:
         _rccl.check(_rccl.lib().pq_comm_init_rank(ctypes.byref(self._comm), self.world, idbuf, self.rank), "pq_comm_init_rank")
         self._ws = None
 
-    def __call__(self, y_local: torch.Tensor, n_total: int) -> torch.Tensor:
+    def comm_ranks(self) -> int:
+        """The rank count RCCL itself reports for the communicator (ncclCommCount)."""
+        n = self._ct.c_int32(0)
+        self._R.check(self._R.lib().pq_comm_count(self._comm, self._ct.byref(n)), "pq_comm_count")
+        return int(n.value)
+
+    def _workspace(self, M, n_total, code, device):
+        need = self._R.lib().pq_allgather_cols_v_workspace_bytes(self.world, M, n_total, code)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _check(self, y_local, n_total):
+        lo, hi = shard_bounds(n_total, self.world, self.rank)
+        if y_local.dim() != 2 or y_local.shape[1] != hi - lo:
+            raise ValueError(f"rank {self.rank}: shard has shape {tuple(y_local.shape)}, expected [M, {hi - lo}]")
+        if y_local.shape[1] > 1 and y_local.stride(1) != 1:
+            raise ValueError("shard rows must be contiguous")
+
+    def gather_into(self, y_local: torch.Tensor, out: torch.Tensor, n_total: int) -> torch.Tensor:
+        """y_local[M, width_r] (any leading dimension) -> out[M, n_total] on every rank (out preallocated)."""
         from . import _lib as L
-        if n_total % self.world or y_local.shape[1] * self.world != n_total:
-            raise ValueError("RcclColumnGather needs equal shards (n_total % world == 0)")
-        y_local = y_local.contiguous()
-        M, n = y_local.shape
+        self._check(y_local, n_total)
+        M = y_local.shape[0]
+        if out.shape != (M, n_total) or out.dtype != y_local.dtype or out.device != y_local.device or (n_total > 1 and out.stride(1) != 1):
+            raise ValueError(f"out must be a row-major [{M}, {n_total}] {y_local.dtype} tensor on {y_local.device}")
         code = L.dtype_code(y_local.dtype)
-        need = self._R.lib().pq_allgather_cols_workspace_bytes(self.world, M, n, code)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=y_local.device)
-        out = torch.empty((M, n_total), dtype=y_local.dtype, device=y_local.device)
+        ws = self._workspace(M, n_total, code, y_local.device)
         with torch.cuda.device(y_local.device):
-            self._R.check(self._R.lib().pq_allgather_cols(self._comm, self.world, y_local.data_ptr(), out.data_ptr(), M, n, code,
-                                                          self._ws.data_ptr(), self._ws.numel(), L.stream_ptr(y_local)),
-                          "pq_allgather_cols")
+            self._R.check(self._R.lib().pq_allgather_cols_v(self._comm, y_local.data_ptr(), L.ld(y_local), out.data_ptr(), L.ld(out), M, n_total,
+                                                            code, ws.data_ptr(), ws.numel(), L.stream_ptr(y_local)), "pq_allgather_cols_v")
+        return out
+
+    def __call__(self, y_local: torch.Tensor, n_total: int) -> torch.Tensor:
+        out = torch.empty((y_local.shape[0], n_total), dtype=y_local.dtype, device=y_local.device)
+        return self.gather_into(y_local, out, n_total)
+
+    def gather_rows_async(self, y_local: torch.Tensor, out: torch.Tensor, m0: int, m1: int, n_total: int) -> None:
+        """Exchange rows [m0, m1) on the communicator's side stream, behind everything already enqueued on torch's current
+        stream; the caller keeps launching on the current stream.  join() before anything reads `out`."""
+        from . import _lib as L
+        self._check(y_local, n_total)
+        M = y_local.shape[0]
+        code = L.dtype_code(y_local.dtype)
+        ws = self._workspace(M, n_total, code, y_local.device)
+        with torch.cuda.device(y_local.device):
+            self._R.check(self._R.lib().pq_allgather_cols_rows_async(self._comm, y_local.data_ptr(), L.ld(y_local), out.data_ptr(), L.ld(out), M, m0, m1,
+                                                                     n_total, code, ws.data_ptr(), ws.numel(), L.stream_ptr(y_local)),
+                          "pq_allgather_cols_rows_async")
+
+    def join(self, device=None) -> None:
+        """torch's current stream waits for every exchange issued so far."""
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self._R.check(self._R.lib().pq_comm_join(self._comm, stream), "pq_comm_join")
+
+    def gather_t(self, yt_local: torch.Tensor, n_total: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Transposed shards yt_local[width_r, M] (contiguous) -> yt[n_total, M]: one contiguous collective, no layout pass."""
+        from . import _lib as L
+        lo, hi = shard_bounds(n_total, self.world, self.rank)
+        if yt_local.dim() != 2 or yt_local.shape[0] != hi - lo or not yt_local.is_contiguous():
+            raise ValueError(f"rank {self.rank}: transposed shard must be a contiguous [{hi - lo}, M] tensor, got {tuple(yt_local.shape)}")
+        M = yt_local.shape[1]
+        if out is None:
+            out = torch.empty((n_total, M), dtype=yt_local.dtype, device=yt_local.device)
+        elif out.shape != (n_total, M) or not out.is_contiguous() or out.dtype != yt_local.dtype or out.device != yt_local.device:
+            raise ValueError(f"out must be a contiguous [{n_total}, {M}] tensor")
+        with torch.cuda.device(yt_local.device):
+            self._R.check(self._R.lib().pq_allgather_rows_t(self._comm, yt_local.data_ptr(), out.data_ptr(), n_total, M, L.dtype_code(yt_local.dtype),
+                                                            L.stream_ptr(yt_local)), "pq_allgather_rows_t")
         return out
 
     def close(self):
@@ -135,39 +191,98 @@ class RcclColumnGather:
             self._comm = self._ct.c_void_p()
 
 
+def gather_rows_t(yt_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """torch.distributed form of RcclColumnGather.gather_t: transposed shards [width_r, M] -> yt[n_total, M].  Row blocks are
+    contiguous, so equal shards are ONE all_gather_into_tensor straight into the result; ragged shards use one broadcast per rank
+    into its row block of the result (no padding, no layout pass)."""
+    world = dist.get_world_size(group)
+    M = yt_local.shape[1]
+    out = yt_local.new_empty((n_total, M))
+    if n_total % world == 0:
+        dist.all_gather_into_tensor(out.view(-1), yt_local.contiguous().view(-1), group=group)
+        return out
+    rank = dist.get_rank(group)
+    for r in range(world):                  # an all-gather-v as one broadcast per rank, each landing in place (as the native form does)
+        a, b = shard_bounds(n_total, world, r)
+        if r == rank:
+            out[a:b].copy_(yt_local)
+        if b > a:
+            dist.broadcast(out[a:b], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+    return out
+
+
 class ColumnShardedQLinear(nn.Module):
-    """qlinear whose int8 weight rows [n0:n1) live on this rank; forward returns the full y[..., N]."""
+    """qlinear whose int8 weight rows [n0:n1) live on this rank; forward returns the full y[..., N].
+
+    layout="rows" (default): the local GEMM writes y[:, n0:n1] shards; the all-gather lands them stacked and one layout pass
+    builds row-major y[M, N].  layout="transposed" (SURVEY.md §8(e) option 1): the local GEMM writes the TRANSPOSED shard
+    yt[n0:n1, :] (pq_qlinear_s8_t, same bits), whose all-gather is contiguous — no staging buffer, no layout kernel; forward
+    returns yt.t(): a [.., M, N] view with strides (1, M) that holds exactly the values of the row-major result (a consumer that
+    needs row-major memory pays the transpose itself; one that indexes logically does not).
+    overlap_chunks > 1 (layout="rows"): the rows are cut into blocks and each block's exchange overlaps the next block's GEMM —
+    natively on the communicator's side stream (native_gather) or through torch.distributed's async collectives."""
 
     def __init__(self, local: qlinear, out_features: int, group=None, native_gather: "RcclColumnGather | None" = None,
-                 overlap_chunks: int = 1):
+                 overlap_chunks: int = 1, layout: str = "rows"):
         super().__init__()
+        if layout not in ("rows", "transposed"):
+            raise ValueError("layout must be 'rows' or 'transposed'")
         self.local, self.out_features, self.group = local, out_features, group
         self.in_features = local.in_features
         self.native_gather = native_gather          # optional: exchange through libpq_rccl.so instead of torch.distributed
         self.overlap_chunks = overlap_chunks        # > 1: row blocks, each block's gather overlapping the next block's GEMM
+        self.layout = layout
 
     @classmethod
-    def from_linear(cls, lin: nn.Linear, group=None, native_gather=None, overlap_chunks: int = 1) -> "ColumnShardedQLinear":
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    def from_linear(cls, lin: nn.Linear, group=None, native_gather=None, overlap_chunks: int = 1, layout: str = "rows",
+                    world=None, rank=None) -> "ColumnShardedQLinear":
+        if world is None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
         lo, hi = shard_bounds(lin.out_features, world, rank)
         sub = nn.Linear(lin.in_features, hi - lo, bias=lin.bias is not None, device=lin.weight.device, dtype=lin.weight.dtype)
         with torch.no_grad():
             sub.weight.copy_(lin.weight[lo:hi])
             if lin.bias is not None:
                 sub.bias.copy_(lin.bias[lo:hi])
-        return cls(qlinear.from_linear(sub), lin.out_features, group, native_gather, overlap_chunks)
+        return cls(qlinear.from_linear(sub), lin.out_features, group, native_gather, overlap_chunks, layout)
+
+    # the three device steps, separate so that host logic can be tested with them stubbed (tests/test_dist_gloo.py)
+    def _quantize(self, x):
+        return quantize(x, axis=-1)                                  # replicated activation: every rank runs K1 itself
+
+    def _local_rows(self, codes, scales, dtype, out=None):
+        return qlinear_s8(codes, scales, self.local.wq, self.local.ws, self.local.bias, dtype, out=out)
+
+    def _local_t(self, codes, scales, dtype):
+        return qlinear_s8_t(codes, scales, self.local.wq, self.local.ws, self.local.bias, dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        xq = quantize(x, axis=-1)                                   # replicated activation: every rank runs K1 itself
-        if self.overlap_chunks > 1 and self.native_gather is None:
-            codes = xq.int_data.reshape(-1, self.in_features)
-
-            def rows(m0, m1):
-                return qlinear_s8(codes[m0:m1], xq.scale[m0:m1], self.local.wq, self.local.ws, self.local.bias, x.dtype)
-            y = gather_columns_overlapped(rows, codes.shape[0], self.out_features, self.overlap_chunks, x.dtype, x.device, self.group)
+        xq = self._quantize(x)
+        codes = xq.int_data.reshape(-1, self.in_features)
+        M = codes.shape[0]
+        if self.layout == "transposed":
+            yt_local = self._local_t(codes, xq.scale, x.dtype)
+            yt = self.native_gather.gather_t(yt_local, self.out_features) if self.native_gather is not None else \
+                gather_rows_t(yt_local, self.out_features, self.group)
+            y = yt.t()                                               # [M, N] view, strides (1, M)
+            return y if x.dim() == 2 else y.unflatten(0, x.shape[:-1])
+        if self.overlap_chunks > 1 and self.native_gather is not None:
+            lo, hi = shard_bounds(self.out_features, self.native_gather.world, self.native_gather.rank)
+            y_local = torch.empty((M, hi - lo), dtype=x.dtype, device=x.device)
+            y = torch.empty((M, self.out_features), dtype=x.dtype, device=x.device)
+            for c in range(self.overlap_chunks):
+                m0, m1 = shard_bounds(M, self.overlap_chunks, c)
+                if m1 > m0:
+                    self._local_rows(codes[m0:m1], xq.scale[m0:m1], x.dtype, out=y_local[m0:m1])
+                    self.native_gather.gather_rows_async(y_local, y, m0, m1, self.out_features)
+            self.native_gather.join(x.device)       # the side stream's reads of y_local are ordered before anything enqueued from here on
             return y.reshape(*x.shape[:-1], self.out_features)
-        y_local = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.local.wq, self.local.ws,
-                             self.local.bias, x.dtype)
+        if self.overlap_chunks > 1:
+            def rows(m0, m1):
+                return self._local_rows(codes[m0:m1], xq.scale[m0:m1], x.dtype)
+            y = gather_columns_overlapped(rows, M, self.out_features, self.overlap_chunks, x.dtype, x.device, self.group)
+            return y.reshape(*x.shape[:-1], self.out_features)
+        y_local = self._local_rows(codes, xq.scale, x.dtype)
         if self.native_gather is not None:
             y = self.native_gather(y_local, self.out_features)
         else:

@@ -143,3 +143,80 @@ def test_gather_columns_overlapped_world2(M, n_total, chunks):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------- ColumnShardedQLinear.forward at world 2 (host logic of the module)
+def _module_worker(rank, world, port, N, M, K, layout, chunks, q):
+    """The module's forward with its three device steps replaced by CPU computations from the numpy oracle (the HIP kernels
+    are covered by the -m gpu tests): what runs here is the real forward() — shard bounds, the choice of exchange, the
+    collectives over gloo, the layout handling — and the result must equal the oracle's unsharded qlinear, bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from oracle import qspec_numpy as Q
+        from protoquant_amd.qtensor import QTensor
+        from protoquant_amd.sharded import ColumnShardedQLinear, shard_bounds
+
+        rng = np.random.default_rng(5)
+        x = Q.from_f32(rng.standard_normal((M, K)).astype(np.float32), 0)
+        w = Q.from_f32((rng.standard_normal((N, K)) * 0.05).astype(np.float32), 0)
+        bias = Q.from_f32((rng.standard_normal(N) * 0.1).astype(np.float32), 0)
+        wq, ws = Q.quantize(w, 0, 1)
+        y_want, xq, xs, _ = Q.qlinear(x, 0, wq, ws, bias)
+        lo, hi = shard_bounds(N, world, rank)
+        bf = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.bfloat16)     # noqa: E731
+
+        import types
+        local = types.SimpleNamespace(in_features=K, out_features=hi - lo, wq=torch.from_numpy(wq[lo:hi]),      # the rank's shard
+                                      ws=torch.from_numpy(ws[lo:hi]), bias=bf(bias[lo:hi]))
+
+        class Stub(ColumnShardedQLinear):
+            def _quantize(self, xt):
+                return QTensor(torch.from_numpy(xq), torch.from_numpy(xs), 1, torch.bfloat16, torch.Size((M, K)))
+
+            def _ref(self, codes, scales):
+                acc = Q.gemm_s8s8s32(codes.numpy(), wq[lo:hi])
+                return Q.epilogue(acc, scales.numpy(), ws[lo:hi], bias[lo:hi], 0)
+
+            def _local_rows(self, codes, scales, dtype, out=None):
+                y = bf(self._ref(codes, scales))
+                if out is not None:
+                    out.copy_(y)
+                    return out
+                return y
+
+            def _local_t(self, codes, scales, dtype):
+                return bf(self._ref(codes, scales)).t().contiguous()
+
+        m = Stub.__new__(Stub)
+        torch.nn.Module.__init__(m)
+        m.local, m.out_features, m.group, m.in_features, m.native_gather, m.overlap_chunks, m.layout = local, N, None, K, None, chunks, layout
+        y = m(bf(x))
+        ok = tuple(y.shape) == (M, N) and torch.equal(y.contiguous().view(torch.int16), bf(y_want).view(torch.int16))
+        if layout == "transposed":
+            ok = ok and y.stride() == (1, M)            # a view of the contiguous y^T: no layout pass happened
+        y3 = m(bf(x).reshape(2, M // 2, K))             # [..., K] inputs
+        ok = ok and tuple(y3.shape) == (2, M // 2, N) and torch.equal(y3.reshape(M, N).contiguous().view(torch.int16), bf(y_want).view(torch.int16))
+        q.put((rank, bool(ok)))
+    except Exception as e:                              # fail fast instead of letting the parent wait for its timeout
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,layout,chunks", [(64, "rows", 1), (63, "rows", 1), (64, "rows", 3), (63, "rows", 2), (64, "transposed", 1), (63, "transposed", 1)])
+def test_column_sharded_module_forward_world2(N, layout, chunks):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_module_worker, args=(r, world, port, N, 12, 40, layout, chunks, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

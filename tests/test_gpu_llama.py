@@ -1,0 +1,55 @@
+"""-m gpu: the Llama call-site integration (protoquant_amd/llama.py): both RMSNorms fused into the quantisation, q/k/v as one
+fused GEMM, the gated MLP — on a small transformers LlamaForCausalLM, against the unfused int8 model and the oracle chain."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from tests.gpu_util import bits, same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pq():
+    import protoquant_amd
+    from protoquant_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return protoquant_amd
+
+
+def test_fused_llama_layers_match_unfused_and_oracle(pq):
+    tr = pytest.importorskip("transformers")
+    import copy
+    from protoquant_amd.llama import RMSNormQuant, fuse_llama_layers
+    torch.manual_seed(0)
+    cfg = tr.LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=2, max_position_embeddings=256)
+    model = tr.LlamaForCausalLM(cfg).to(torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        for l in model.model.layers:        # non-trivial norm weights
+            l.input_layernorm.weight.copy_((1 + 0.1 * torch.randn(256)).to(torch.bfloat16)); l.post_attention_layernorm.weight.copy_((1 + 0.1 * torch.randn(256)).to(torch.bfloat16))
+    l0 = model.model.layers[0]
+    wts = {n: getattr(l0.self_attn, n).weight.detach().cpu().clone() for n in ("q_proj", "k_proj", "v_proj")}
+    nw = l0.input_layernorm.weight.detach().cpu().clone()
+    pq.swap_linears(model, fuse_gated_mlp=True)
+    unfused = copy.deepcopy(model)
+    assert fuse_llama_layers(model) == 2
+    assert isinstance(model.model.layers[0].input_layernorm, RMSNormQuant) and isinstance(model.model.layers[1].post_attention_layernorm, RMSNormQuant)
+    ids = torch.randint(0, 512, (2, 96), device="cuda")
+    with torch.no_grad():
+        a, b = unfused(ids).logits, model(ids).logits
+    # the fused norm stores the same bf16 activation as the eager chain, so the whole model agrees bit for bit
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), float((a.float() - b.float()).abs().max())
+    # layer 0's fused norm + qkv against the oracle chain
+    x = torch.randn(50, 256, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        h = model.model.layers[0].input_layernorm(x)
+        attn = model.model.layers[0].self_attn
+        q, k, v = attn.q_proj(h), attn.k_proj(h), attn.v_proj(h)
+    hq, hs, _ = C.rmsnorm_quant_rowwise(bits(x), bits(nw), cfg.rms_norm_eps, 0)
+    same(h.int_data, hq, "norm codes"); same(h.scale, hs, "norm scales")
+    for out, n in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")):
+        same(out.contiguous(), C.qlinear_s8(hq, hs, *C.quant_rowwise(bits(wts[n]), 0), None, 0), "fused " + n)
+    assert attn.qkv_fused._outs is None          # the shared result is released after its third consumer
