@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--torch-gather", action="store_true", help="tp: exchange through torch.distributed instead of libpq_rccl.so")
     ap.add_argument("--no-dp-leg", action="store_true", help="tp: skip the extra dp figure")
     ap.add_argument("--no-consistency-check", action="store_true")
-    ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b"], default="qlinear",
+    ap.add_argument("--layers", type=int, default=32, help="llama8b workload: decoder layers (32 = the model)")
+    ap.add_argument("--no-layer-fusion", action="store_true", help="llama8b workload: skip fuse_llama_layers (stock norms, separate q/k/v GEMMs)")
+    ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b", "llama8b-linears"], default="qlinear",
                     help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +199,7 @@ def run_mlp(args):
                       "cpu_baseline": None}), flush=True)
 
 
-def run_llama8b(args):
+def run_llama8b_linears(args):
     """BASELINE configs[3], linears only: 32 layers x {fused qkv 4096->6144, o 4096->4096, fused gate+up 4096->28672,
     down 14336->4096} + lm_head 4096->128256 at M = 4096 tokens (bs 1, seq 4096): 61.48 TOP of int8 GEMM per pass.
     Synthetic int8 weights (gaussian codes) and scales; every activation quantisation (K1) is included; attention,
@@ -277,11 +279,107 @@ def run_llama8b(args):
                       "cpu_baseline": None}), flush=True)
 
 
+def run_llama8b(args):
+    """BASELINE configs[3] as a MODEL: transformers' LlamaForCausalLM at Llama-3-8B dims (hidden 4096, intermediate 14336, 32
+    layers, 32 heads / 8 KV heads, vocab 128256) with synthetic weights initialised on the GPU, every nn.Linear swapped to qlinear
+    (swap_linears: the product path quantises the bf16 weights), gated MLPs as GatedMLP, both RMSNorms of every layer fused into
+    the activation quantisation and q/k/v as one fused GEMM (protoquant_amd.llama.fuse_llama_layers).  Prefill, bs 1, seq 4096.
+    Reported: end-to-end latency; the time of the int8 linear path (every quantisation + GEMM launch, measured with HIP events
+    around those modules) and its TOPS over the 61.48 TOP of linear work; attention / rope / residual / embedding / final norm
+    (stock torch-ROCm ops) as the remainder."""
+    import transformers as tr
+    import protoquant_amd as pq
+    from protoquant_amd.llama import RMSNormQuant, fuse_llama_layers
+    dev = torch.device("cuda", 0)
+    S = args.tokens
+    cfg = tr.LlamaConfig(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
+                         num_key_value_heads=8, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0, attn_implementation="sdpa")
+    t0 = time.perf_counter()
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            model = tr.LlamaForCausalLM(cfg).eval()
+        finally:
+            torch.set_default_dtype(prev)
+    pq.swap_linears(model, fuse_gated_mlp=True)
+    nfused = 0 if args.no_layer_fusion else fuse_llama_layers(model)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    ids = torch.randint(0, cfg.vocab_size, (1, S), device=dev)
+
+    # HIP events around every int8-path module (fused norm+quant, qlinear / FusedQLinear / GatedMLP); attention's projections
+    # sit inside self_attn, so the hooks go on the leaves
+    from protoquant_amd.llama import _FusedSlice, _SharedFused
+    inside = set()                       # qlinears that a timed parent already covers
+    for m in model.modules():
+        if isinstance(m, (pq.GatedMLP, _SharedFused)):
+            inside.update(id(sub) for sub in m.modules() if sub is not m)
+    timed = [m for m in model.modules()
+             if isinstance(m, (RMSNormQuant, pq.GatedMLP)) or (isinstance(m, _FusedSlice) and m.index == 0)
+             or (isinstance(m, (pq.qlinear, pq.FusedQLinear)) and id(m) not in inside)]
+    spans, timing = [], {"on": False}
+
+    def pre(mod, inp):
+        if timing["on"]:
+            mod._span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            mod._span[0].record()
+
+    def post(mod, inp, out):
+        if timing["on"]:
+            mod._span[1].record()
+            spans.append(mod._span)
+    for m in timed:
+        m.register_forward_pre_hook(pre); m.register_forward_hook(post)
+
+    def fwd():
+        with torch.no_grad():
+            return model(ids, use_cache=False, logits_to_keep=0).logits
+    for _ in range(max(1, args.warmup if args.warmup < 5 else 2)):
+        out = fwd()
+    torch.cuda.synchronize()
+    assert out.shape == (1, S, cfg.vocab_size)
+    lat = []
+    for _ in range(max(3, min(args.steps, 10))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); fwd(); torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    e2e = lat[len(lat) // 2]
+    timing["on"] = True
+    lin_t = []
+    for _ in range(3):
+        spans.clear()
+        fwd(); torch.cuda.synchronize()
+        lin_t.append(sum(a.elapsed_time(b) for a, b in spans) * 1e-3)
+    timing["on"] = False
+    lin_t.sort()
+    t_lin = lin_t[len(lin_t) // 2]
+    L, H, I, V = cfg.num_hidden_layers, 4096, 14336, cfg.vocab_size
+    ops = L * (2.0 * S * 6144 * H + 2.0 * S * H * H + 2.0 * S * 2 * I * H + 2.0 * S * H * I) + 2.0 * S * V * H
+    print(json.dumps({"metric": "int8 TOPS of the linear path + end-to-end prefill latency, Llama-3-8B (every nn.Linear as qlinear), bs 1 seq 4096",
+                      "value": round(ops / t_lin / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(lat), "warmup": 2, "ms_per_step": round(e2e * 1e3, 3),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+                      "config": {"workload": f"transformers LlamaForCausalLM at Llama-3-8B dims ({L} layers), synthetic weights, swap_linears(fuse_gated_mlp) + fuse_llama_layers, prefill bs 1 seq {S} (BASELINE configs[3])",
+                                 "layers_fused": nfused, "attention": "stock torch-ROCm (sdpa), rope / residual / embedding / final norm stock",
+                                 "int8_ops_per_step": ops, "build_seconds": round(t_build, 1)},
+                      "end_to_end_ms": round(e2e * 1e3, 3), "end_to_end_ms_min": round(lat[0] * 1e3, 3),
+                      "linear_path_ms": round(t_lin * 1e3, 3), "other_ops_ms": round((e2e - t_lin) * 1e3, 3),
+                      "roofline": {"bound": "mfma", "achieved": round(ops / t_lin / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                                   "frac": round(ops / t_lin / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
+                                   "note": "all int8-path launches of the forward: fused RMSNorm+quant (x2 per layer), fused qkv, o, fused gate+up, silu*mul+quant, down, lm_head (its own K1); HIP events around those modules"},
+                      "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
     if args.workload == "llama8b":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"
-        return run_llama8b(args)
+        return run_llama8b(args) if args.tokens > 512 else run_llama8b_linears(args)
+    if args.workload == "llama8b-linears":
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b-linears is a 1-GPU measurement"
+        return run_llama8b_linears(args)
     if args.workload == "mlp":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mlp is a 1-GPU measurement"
         return run_mlp(args)

@@ -10,7 +10,7 @@
 
 namespace pq {
 template <int DT> void quant_rowwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
-template <int DT> void quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template <int DT> hipError_t quant_colwise_dispatch(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template <int DT> void silu_mul_quant_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
@@ -23,6 +23,7 @@ template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
+void set_k1_rpw(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -179,6 +180,7 @@ int32_t pq_set_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
     return PQ_OK;
@@ -207,11 +209,13 @@ int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t col
         return fail(PQ_ERR_BAD_ARG, "pq_quant_colwise: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
     if (cols == 0) return PQ_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e;
     switch (dtype) {
-        case PQ_BF16: pq::quant_colwise_dispatch<PQ_BF16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
-        case PQ_FP16: pq::quant_colwise_dispatch<PQ_FP16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
-        default: pq::quant_colwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        case PQ_BF16: e = pq::quant_colwise_dispatch<PQ_BF16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        case PQ_FP16: e = pq::quant_colwise_dispatch<PQ_FP16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
+        default: e = pq::quant_colwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
     }
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_quant_colwise: hipMemsetAsync of the amax scratch: %s", hipGetErrorString(e));
     return check_launch("pq_quant_colwise");
 }
 

@@ -8,96 +8,105 @@ namespace pq {
 
 // ------------------------------------------------------------------------------------------------
 // K1 vector path.  TPR threads own one row; thread t holds 16-byte vectors t, t+TPR, ... (VPT of
-// them) so every wave-instruction reads 1 KiB contiguous.  A row group (wave for TPR=64, block for
-// TPR=256) walks rows g, g+G, g+2G, ... two at a time with both rows' loads issued up front, so one
-// row's HBM latency hides under the other's arithmetic and stores.  Algorithmic traffic: read once,
-// write 1 B/elem + 4 B/row.
-template <int DT, int VPT, int TPR>
+// them) so every wave-instruction reads 1 KiB contiguous.  The row stays in registers between the amax
+// reduction and the encode: ONE HBM read.  Algorithmic traffic: read once, write 1 B/elem + 4 B/row.
+// RPW (TPR = 64 only): rows per wave; 2 issues both rows' loads up front (an experiment that measured slower: see
+// launch_rowwise_vec).
+template <int DT, int VPT, int TPR, int RPW = 1>
 __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restrict__ x, int64_t rows, int nvec,
                                                          int64_t ldx_bytes, int8_t* __restrict__ q, int64_t ldq,
                                                          float* __restrict__ scale) {
+    static_assert(RPW == 1 || TPR == kWave, "several rows per wave only in the wave-per-row layout");
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     constexpr int RPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
-    int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
-    const bool active = row < rows;                 // only the last block can hold inactive row groups (TPR = 64)
-    row = active ? row : rows - 1;
-    const uint8_t* xr = x + row * ldx_bytes;
+    const int64_t row0 = ((int64_t)blockIdx.x * RPB + threadIdx.x / TPR) * RPW;
 
     // Loads are UNCONDITIONAL (clamped address): a per-element "load or zero" select makes hipcc branch
     // around every load and wait vmcnt(0) each time.  Duplicates of the clamped tail vector do not change a max.
-    v4u v[VPT];
+    v4u v[RPW][VPT];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int idx = i * TPR + t;
-        v[i] = *reinterpret_cast<const v4u*>(xr + (int64_t)(idx < nvec ? idx : nvec - 1) * 16);
-    }
-    // ---- amax (Q2) on bit patterns
-    uint32_t ab = 0;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int64_t row = row0 + rr < rows ? row0 + rr : rows - 1;
+        const uint8_t* xr = x + row * ldx_bytes;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) ab = vec_amax_bits<DT>(v[i], ab);
-    ab = wave_max_u32(ab);
-    __shared__ uint32_t part[256 / kWave];
-    if constexpr (TPR > kWave) {
-        if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
-    }
-    const bool has_nan = amax_bits_has_nan<DT>(ab);
-    float amax = amax_bits_to_f32<DT>(ab);
-    if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare, row re-read from L2
-        amax = 0.0f;
-#pragma unroll 1
         for (int i = 0; i < VPT; ++i) {
             const int idx = i * TPR + t;
-            if (idx < nvec) {
-                float f[EPV];
-                Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+            v[rr][i] = *reinterpret_cast<const v4u*>(xr + (int64_t)(idx < nvec ? idx : nvec - 1) * 16);
+        }
+    }
+    __shared__ uint32_t part[256 / kWave];
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
+    for (int rr = 0; rr < RPW; ++rr) {
+        const bool active = row0 + rr < rows;           // only the last block can hold inactive rows
+        const int64_t row = active ? row0 + rr : rows - 1;
+        const uint8_t* xr = x + row * ldx_bytes;
+        // ---- amax (Q2) on bit patterns
+        uint32_t ab = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) ab = vec_amax_bits<DT>(v[rr][i], ab);
+        ab = wave_max_u32(ab);
+        if constexpr (TPR > kWave) {
+            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
+        }
+        const bool has_nan = amax_bits_has_nan<DT>(ab);
+        float amax = amax_bits_to_f32<DT>(ab);
+        if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare, row re-read from L2
+            amax = 0.0f;
+#pragma unroll 1
+            for (int i = 0; i < VPT; ++i) {
+                const int idx = i * TPR + t;
+                if (idx < nvec) {
+                    float f[EPV];
+                    Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
+                }
+            }
+            amax = wave_max(amax);
+            if constexpr (TPR > kWave) {
+                __syncthreads();
+                if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
             }
         }
-        amax = wave_max(amax);
-        if constexpr (TPR > kWave) {
-            __syncthreads();
-            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
-            __syncthreads();
+        const float s = scale_of(amax);
+        if (!active) { if constexpr (RPW == 1) return; else continue; }
+        if (t == 0) scale[row] = s;
+        int8_t* qr = q + row * ldq;
+        auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
+            if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
+            else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
+        };
+        if (!has_nan && scale_fast_ok(s)) {       // the hot path: no division per element, results identical to x / s
+            const float r = 1.0f / s;
 #pragma unroll
-            for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
-        }
-    }
-    const float s = scale_of(amax);
-    if (!active) return;
-    if (t == 0) scale[row] = s;
-    int8_t* qr = q + row * ldq;
-    auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
-        if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
-        else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
-    };
-    if (!has_nan && scale_fast_ok(s)) {       // the hot path: no division per element, results identical to x / s
-        const float r = 1.0f / s;
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = i * TPR + t;
-            float f[EPV];
-            Unpack<DT, EPV>::run(v[i], f);
-            uint32_t pk[EPV / 4];
-            fast_encode<EPV>(f, s, r, pk);
-            if (idx < nvec) store_vec(idx, pk);
-        }
-    } else {                                  // uniform per row group: true division (NaN/Inf data, extreme scales)
-#pragma unroll 1
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = i * TPR + t;
-            if (idx < nvec) {
+            for (int i = 0; i < VPT; ++i) {
+                const int idx = i * TPR + t;
                 float f[EPV];
-                Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+                Unpack<DT, EPV>::run(v[rr][i], f);
                 uint32_t pk[EPV / 4];
+                fast_encode<EPV>(f, s, r, pk);
+                if (idx < nvec) store_vec(idx, pk);
+            }
+        } else {                                  // uniform per row group: true division (NaN/Inf data, extreme scales)
+#pragma unroll 1
+            for (int i = 0; i < VPT; ++i) {
+                const int idx = i * TPR + t;
+                if (idx < nvec) {
+                    float f[EPV];
+                    Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
+                    uint32_t pk[EPV / 4];
 #pragma unroll
-                for (int g = 0; g < EPV / 4; ++g)
-                    pk[g] = pack4(code_of(f[4 * g], s), code_of(f[4 * g + 1], s), code_of(f[4 * g + 2], s), code_of(f[4 * g + 3], s));
-                store_vec(idx, pk);
+                    for (int g = 0; g < EPV / 4; ++g)
+                        pk[g] = pack4(code_of(f[4 * g], s), code_of(f[4 * g + 1], s), code_of(f[4 * g + 2], s), code_of(f[4 * g + 3], s));
+                    store_vec(idx, pk);
+                }
             }
         }
     }
@@ -308,12 +317,32 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
 // host-side launchers (called from pq_api.hip)
 static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
+int g_k1_rpw = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_K1_RPW"))
+void set_k1_rpw(int v) { g_k1_rpw = v; }
+
 template <int DT, int TPR>
 static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, int64_t ldx_bytes, int8_t* q,
                                int64_t ldq, float* scale, hipStream_t st) {
     constexpr int RPB = 256 / TPR;
-    const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+    if constexpr (TPR == kWave) {
+        // two rows per wave: built to overlap one row's stores with the other's loads, and measured SLOWER on every shape
+        // (profiles/r02_k1_rows_per_wave.txt: 4096 x 4096 9.56 -> 10.49 us, 16384 x 4096 31.6 -> 32.5 us): the one-row kernel
+        // already runs at 76-80 % of 8 TB/s once the problem is large enough (4096 x 8192, 16384 x 4096); what keeps
+        // 4096 x 4096 at 66 % is ~1.5 us of launch ramp and tail on an 8 us transfer, not the phase structure.  Kept
+        // selectable (pq_set_option("PQ_K1_RPW", "2")) so the measurement can be repeated.
+        const bool two = g_k1_rpw == 2;
+        if (two && vpt <= 8) {
+            const dim3 grid2((unsigned)((rows + 2 * RPB - 1) / (2 * RPB))), block(256);
+            switch (vpt) {
+                case 1: quant_rowwise_vec<DT, 1, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 2: quant_rowwise_vec<DT, 2, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 4: quant_rowwise_vec<DT, 4, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                default: quant_rowwise_vec<DT, 8, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+            }
+        }
+    }
+    const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
     switch (vpt) {
         case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
         case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
@@ -344,8 +373,8 @@ void quant_rowwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
 }
 
 template <int DT>
-void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t ldx, int8_t* q, int64_t ldq,
-                            float* scale, hipStream_t st) {
+hipError_t quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t ldx, int8_t* q, int64_t ldq,
+                                  float* scale, hipStream_t st) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) && aligned(q, EPV);
     const int64_t ncolv = vec_ok ? cols / EPV : cols;
@@ -358,7 +387,8 @@ void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((ncolv + 63) / 64)), block(256);
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const int64_t ldb = ldx * Elem<DT>::kBytes;
-    (void)hipMemsetAsync(scale, 0, (size_t)cols * sizeof(float), st);
+    const hipError_t me = hipMemsetAsync(scale, 0, (size_t)cols * sizeof(float), st);   // amax scratch = 0 (the atomicMax identity)
+    if (me != hipSuccess) return me;                                                      // never launch on an un-zeroed scratch
     if (rows > 0) {
         if (vec_ok) {
             col_amax<DT, true><<<grid, block, 0, st>>>(xb, rows, ncolv, ldb, reinterpret_cast<uint32_t*>(scale), rpb);
@@ -369,6 +399,7 @@ void quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
         }
     }
     col_finalize<<<dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st>>>(scale, cols);
+    return hipSuccess;
 }
 
 template <int ODT>
@@ -387,9 +418,9 @@ void dequant_dispatch(const int8_t* q, int64_t ldq, const float* scale, int axis
 template void quant_rowwise_dispatch<PQ_BF16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template void quant_rowwise_dispatch<PQ_FP16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template void quant_rowwise_dispatch<PQ_F32>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
-template void quant_colwise_dispatch<PQ_BF16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
-template void quant_colwise_dispatch<PQ_FP16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
-template void quant_colwise_dispatch<PQ_F32>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template hipError_t quant_colwise_dispatch<PQ_BF16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template hipError_t quant_colwise_dispatch<PQ_FP16>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
+template hipError_t quant_colwise_dispatch<PQ_F32>(const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, hipStream_t);
 template void dequant_dispatch<PQ_BF16>(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template void dequant_dispatch<PQ_FP16>(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template void dequant_dispatch<PQ_F32>(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);

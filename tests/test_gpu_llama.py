@@ -48,7 +48,7 @@ def test_fused_llama_layers_match_unfused_and_oracle(pq):
         h = model.model.layers[0].input_layernorm(x)
         attn = model.model.layers[0].self_attn
         q, k, v = attn.q_proj(h), attn.k_proj(h), attn.v_proj(h)
-    hq, hs, _ = C.rmsnorm_quant_rowwise(bits(x), bits(nw), cfg.rms_norm_eps, 0)
+    hq, hs = C.rmsnorm_quant_rowwise(bits(x), bits(nw), cfg.rms_norm_eps, 0)[:2]
     same(h.int_data, hq, "norm codes"); same(h.scale, hs, "norm scales")
     for out, n in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")):
         same(out.contiguous(), C.qlinear_s8(hq, hs, *C.quant_rowwise(bits(wts[n]), 0), None, 0), "fused " + n)
