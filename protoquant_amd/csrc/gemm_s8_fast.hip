@@ -557,12 +557,20 @@ template void launch_splitk_reduce<PQ_F32>(const int32_t*, int, int64_t, int64_t
 // One s_barrier per K-tile.  Same LDS image as the big kernel: [128 rows][128 B], 16-byte chunk c of row r at c ^ ((r>>1)&7).
 constexpr int R_TILE = 128, R_NBUF = 4, R_OPER = 128 * FBK /* 16 KiB */, R_BUF = 2 * R_OPER, R_LDS = R_NBUF * R_BUF;
 
-template <int OUT>
-__global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
+// LC (loader / consumer split, 8 waves): measured with in-kernel stamps, the 4-wave form spends ~1080 cycles per K-tile against
+// 512 of MFMA because every LDS-DMA piece holds the issuing wave for 60-180 cycles (the texture path takes ~22 cycles per 1-KiB
+// piece per CU and the wave issues in order) — with ONE wave per SIMD the matrix pipe idles through each of them.  LC puts a
+// second wave on every SIMD whose only job is the DMA stream: waves 0-3 (consumers) run the pure MFMA + ds_read stream, waves
+// 4-7 (loaders) issue all 32 pieces of a K-tile (8 each) and wait for them; one s_barrier per K-tile joins the two roles
+// exactly where the 4-wave form has its barrier, so the ring protocol (and every result bit) is unchanged.
+template <int OUT, bool LC = false>
+__global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
                                                        int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[R_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LC && wave >= 4;                                 // (4-wave form: every wave loads and computes)
+    const int w = wave & 3;                                            // index inside the role
     const int wp = w >> 1, wq = w & 1;
 
     int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
@@ -618,14 +626,32 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
 
     const int NT = K / FBK;
     // ---- prologue: up to 4 tiles in flight, wait for tile 0, read its fragments
+    if (!LC || loader) {
 #pragma unroll
-    for (int b = 0; b < R_NBUF; ++b)
-        if (b < NT) static_for<8>([&](auto gc) { dma_item(b, gc); });
-    if (NT >= 4) __builtin_amdgcn_s_waitcnt(0x4078);        // vmcnt(24): 3 tiles may still be in flight
-    else if (NT == 3) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
-    else if (NT == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8)
-    else __builtin_amdgcn_s_waitcnt(0x0070);
+        for (int b = 0; b < R_NBUF; ++b)
+            if (b < NT) static_for<8>([&](auto gc) { dma_item(b, gc); });
+        if (NT >= 4) __builtin_amdgcn_s_waitcnt(0x4078);        // vmcnt(24): 3 tiles may still be in flight
+        else if (NT == 3) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
+        else if (NT == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+    }
     __builtin_amdgcn_s_barrier();
+    if constexpr (LC) {
+        if (loader) {
+            // the loader's K-loop: the same waits and the same barrier as the consumers' tiles, then the 8 pieces of tile kt+4
+            for (int kt = 0; kt < NT; ++kt) {
+                const int rem = NT - 1 - kt;
+                if (rem > 0) {
+                    if (rem >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 15));
+                    else if (rem == 2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(8, 15));
+                    else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (rem >= R_NBUF) static_for<8>([&](auto gc) { dma_item(kt & 3, gc); });
+            }
+            return;
+        }
+    }
     static_for<16>([&](auto ic) { read_item(0, fa, ic); });
 
     // one K-tile: 32 MFMAs on `cur`; in their shadows the 16 fragment reads of tile kt+1 into `nxt`, then the 8 DMA pieces
@@ -635,7 +661,8 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
         const int rem = NT - 1 - kt;                          // tiles after this one
         if (rem > 0) {
             // tile kt+1 must have landed: tiles kt+2, kt+3 (8 pieces each per wave) may stay in flight
-            if (rem >= 3) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
+            if constexpr (LC) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   // consumer: its fragment reads only (the loaders wait for the DMA)
+            else if (rem >= 3) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
             else if (rem == 2) __builtin_amdgcn_s_waitcnt(0x0078); // vmcnt(8)  lgkmcnt(0)
             else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0)  lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
@@ -647,10 +674,13 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
             constexpr int x = decltype(xc)::value, ks = x >> 4, i = (x >> 2) & 3, j = x & 3;
             // accumulators pinned in AGPRs through the asm form: with one wave per SIMD hipcc otherwise splits them between
             // the two register files and pays 4 v_accvgpr_write + s_nop in front of every other MFMA (measured 44 % -> see DESIGN)
-            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[ks * 4 + i]), "v"(cur[8 + ks * 4 + j]));
+            // (LC: two waves per SIMD share a 256-register budget, which hipcc halves as soon as a kernel names AGPRs — the builtin
+            // keeps all of it as arch VGPRs, as in the big kernel)
+            if constexpr (LC) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur[ks * 4 + i], cur[8 + ks * 4 + j], acc[i][j], 0, 0, 0);
+            else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[ks * 4 + i]), "v"(cur[8 + ks * 4 + j]));
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (x < 16) read_item(nbuf, nxt, xc);      // (last tile: reads a stale slot, values unused)
-            else if constexpr (x < 24) { if (more) dma_item(kt & 3, std::integral_constant<int, x - 16>{}); }
+            else if constexpr (x < 24 && !LC) { if (more) dma_item(kt & 3, std::integral_constant<int, x - 16>{}); }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -660,11 +690,13 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
 
     // the asm MFMAs are invisible to hipcc's hazard tracking: drain the pipe, then pass every accumulator through an empty
     // asm so that no v_accvgpr_read can be scheduled above the drain
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (!LC) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+    }
 
     // ---- epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n of one m per accumulator
     using O = typename OutElem<OUT>::type;
@@ -725,11 +757,15 @@ __global__ __launch_bounds__(256) void gemm_s8_ring128(const int8_t* __restrict_
     }
 }
 
+bool g_ring_lc = true;      // loader / consumer split (pq_set_option("PQ_RING_LC", "0") restores the 4-wave form)
+void set_ring_lc(bool v) { g_ring_lc = v; }
+
 template <int OUT>
 void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
                          int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + R_TILE - 1) / R_TILE), tiles_n = (int)((N + R_TILE - 1) / R_TILE);
-    gemm_s8_ring128<OUT><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+    if (g_ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+    else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
 }
 template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 
 #include "gemm_epilogue.h"
@@ -24,6 +25,7 @@ template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
+void set_ring_lc(bool);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -64,6 +66,10 @@ Variant parse_variant(const char* e) {
 struct Options {
     int variant = V_AUTO;
     bool no_tailsplit = false, no_splitk = false;
+    // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
+    // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
+    int (*roctx_push)(const char*) = nullptr;
+    int (*roctx_pop)() = nullptr;
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -72,11 +78,30 @@ const Options& options() {
         g_opt.variant = parse_variant(getenv("PQ_FORCE_VARIANT"));
         g_opt.no_tailsplit = getenv("PQ_NO_TAILSPLIT") != nullptr;
         g_opt.no_splitk = getenv("PQ_NO_SPLITK") != nullptr;
+        if (const char* r = getenv("PQ_ROCTX")) {
+            if (*r && *r != '0') {
+                void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    g_opt.roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                    g_opt.roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                    if (!g_opt.roctx_push || !g_opt.roctx_pop) g_opt.roctx_push = nullptr, g_opt.roctx_pop = nullptr;
+                }
+            }
+        }
         if (const char* e = getenv("PQ_SKINNY_RB")) pq::set_skinny_rb(*e == '2' ? 2 : (*e == '1' ? 1 : 0));
     });
     return g_opt;
 }
 Variant forced_variant() { return static_cast<Variant>(options().variant); }
+
+struct Range {      // roctx range for the lifetime of one C-ABI call (host side: it brackets the launches, which are asynchronous)
+    bool on;
+    explicit Range(const char* name) : on(options().roctx_push != nullptr) { if (on) options().roctx_push(name); }
+    ~Range() { if (on) options().roctx_pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 
 Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     const bool ok = pq::gemm_fast_eligible(a, lda, b, ldb, M, N, K);
@@ -180,6 +205,7 @@ int32_t pq_set_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
@@ -189,6 +215,7 @@ const char* pq_last_error(void) { return g_err; }
 
 int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, int8_t* q,
                          int64_t ld_q, float* scale, void* stream) {
+    Range range_("pq:quant_rowwise (K1)");
     if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise: unknown dtype %d", dtype);
     if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale))
         return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
@@ -204,6 +231,7 @@ int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t col
 
 int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, int8_t* q,
                          int64_t ld_q, float* scale, void* stream) {
+    Range range_("pq:quant_colwise (K2)");
     if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_colwise: unknown dtype %d", dtype);
     if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (cols > 0 && !scale))
         return fail(PQ_ERR_BAD_ARG, "pq_quant_colwise: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
@@ -221,6 +249,7 @@ int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t col
 
 int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows,
                                   int64_t cols, int8_t* q, int64_t ld_q, float* scale, void* h_out, int64_t ld_h, void* stream) {
+    Range range_("pq:silu_mul_quant (K1s)");
     if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_quant_rowwise: unknown dtype %d", dtype);
     if (bad_mat(g, rows, cols, ld_g) || bad_mat(u, rows, cols, ld_u) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale) ||
         (h_out && ld_h < cols))
@@ -237,6 +266,7 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
 
 int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight, float eps, int32_t dtype, int64_t rows, int64_t cols,
                                  int8_t* q, int64_t ld_q, float* scale, void* h_out, int64_t ld_h, void* stream) {
+    Range range_("pq:rmsnorm_quant (K1n)");
     if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_rmsnorm_quant_rowwise: unknown dtype %d", dtype);
     if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && !scale) || (rows > 0 && cols > 0 && !weight) ||
         (h_out && ld_h < cols) || cols >= (1 << 24) || !(eps >= 0.0f))
@@ -258,6 +288,7 @@ int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight
 
 int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t axis, int64_t rows, int64_t cols,
                    void* out, int64_t ld_out, int32_t out_dtype, void* stream) {
+    Range range_("pq:dequant");
     if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_dequant: unknown dtype %d", out_dtype);
     if (axis != 0 && axis != 1) return fail(PQ_ERR_BAD_ARG, "pq_dequant: axis must be 0 or 1, got %d", axis);
     if (bad_mat(q, rows, cols, ld_q) || bad_mat(out, rows, cols, ld_out) || (rows > 0 && cols > 0 && !scale))
@@ -274,6 +305,7 @@ int32_t pq_dequant(const int8_t* q, int64_t ld_q, const float* scale, int32_t ax
 
 int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, int32_t* c, int64_t ldc,
                         int64_t M, int64_t N, int64_t K, void* stream) {
+    Range range_("pq:gemm_s8s8s32 (K3)");
     if (M < 0 || N < 0 || K < 0 || bad_mat(a, M, K, lda) || bad_mat(b, N, K, ldb) || bad_mat(c, M, N, ldc))
         return fail(PQ_ERR_BAD_ARG, "pq_gemm_s8s8s32: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldc);
     if (M == 0 || N == 0) return PQ_OK;
@@ -310,6 +342,7 @@ size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 // the GEMM + epilogue of one (M x N x K, A rows x B rows) problem whose EpiArgs are already in the kernel's orientation
 static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
                             int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+    Range range_("pq:qlinear_s8 (K3+K4)");
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.

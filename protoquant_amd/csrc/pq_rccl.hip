@@ -7,7 +7,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 
 #include "../../include/pq_rccl.h"
 
@@ -18,6 +21,29 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 int elem_bytes(int32_t dtype) { return dtype == 2 ? 4 : 2; }
+
+// PQ_ROCTX=1: roctx ranges around the exchange entry points (as in libpq_hip.so); read once
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const Roctx& roctx() {
+    static Roctx r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("PQ_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        r.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        r.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!r.push || !r.pop) r = Roctx{};
+    });
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* n) : on(roctx().push != nullptr) { if (on) roctx().push(n); }
+    ~Range() { if (on) roctx().pop(); }
+};
 
 // The handle behind the void* of the ABI: the RCCL communicator plus what the overlapped exchange needs — a side stream
 // and two events, created once at init so that no call allocates.
@@ -223,6 +249,7 @@ int32_t pq_unstack_cols_v(const void* stacked, void* y_full, int64_t ld_full, in
 
 int32_t pq_allgather_cols(void* comm, int32_t nranks, const void* y_shard, void* y_full, int64_t M, int64_t n_shard,
                           int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    Range range_("pq:allgather_cols");
     if (!comm || nranks < 1 || M < 0 || n_shard < 0 || dtype < 0 || dtype > 2) return fail(1, "pq_allgather_cols: bad arguments");
     if (nranks != H(comm)->nranks) return fail(1, "pq_allgather_cols: nranks %d != communicator's %d", nranks, H(comm)->nranks);
     const size_t need = pq_allgather_cols_workspace_bytes(nranks, M, n_shard, dtype);
@@ -242,6 +269,7 @@ size_t pq_allgather_cols_v_workspace_bytes(int32_t nranks, int64_t M, int64_t n_
 
 int32_t pq_allgather_cols_v(void* comm, const void* y_shard, int64_t ld_shard, void* y_full, int64_t ld_full, int64_t M,
                             int64_t n_total, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    Range range_("pq:allgather_cols_v");
     if (!comm || M < 0 || n_total < 0 || dtype < 0 || dtype > 2 || ld_full < n_total) return fail(1, "pq_allgather_cols_v: bad arguments");
     PqComm* h = H(comm);
     if (M == 0 || n_total == 0) return 0;
@@ -283,6 +311,7 @@ int32_t pq_comm_join(void* comm, void* compute_stream) {
 }
 
 int32_t pq_allgather_rows_t(void* comm, const void* yt_shard, void* yt_full, int64_t n_total, int64_t M, int32_t dtype, void* stream) {
+    Range range_("pq:allgather_rows_t");
     if (!comm || n_total < 0 || M < 0 || dtype < 0 || dtype > 2) return fail(1, "pq_allgather_rows_t: bad arguments");
     PqComm* h = H(comm);
     if (n_total == 0 || M == 0) return 0;
@@ -313,6 +342,7 @@ size_t pq_reduce_scatter_rows_workspace_bytes(int32_t nranks, int64_t m_shard, i
 
 int32_t pq_reduce_scatter_rows(void* comm, int32_t nranks, const float* partial, void* y_rows, int64_t m_shard, int64_t N,
                                int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    Range range_("pq:reduce_scatter_rows");
     if (!comm || nranks < 1 || m_shard < 0 || N < 0 || out_dtype < 0 || out_dtype > 2) return fail(1, "pq_reduce_scatter_rows: bad arguments");
     const size_t count = (size_t)m_shard * (size_t)N;
     if (count == 0) return 0;

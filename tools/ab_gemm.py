@@ -36,7 +36,17 @@ def main():
     ap.add_argument("--bias", action="store_true")
     ap.add_argument("--eager", action="store_true", help="eager back-to-back launches instead of graph replays")
     a = ap.parse_args()
-    libs = [(s.split("=")[0], load(s.split("=")[1])) for s in a.libs]
+    libs = []
+    for spec in a.libs:            # name=path[@OPT=VAL,...]: options go through pq_set_option (load a COPY of the .so for a second setting)
+        name, rest = spec.split("=", 1)
+        path, _, opts = rest.partition("@")
+        Lh = load(path)
+        for o in filter(None, opts.split(",")):
+            k, v = o.split("=")
+            Lh.pq_set_option.restype = i32
+            Lh.pq_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+            assert Lh.pq_set_option(k.encode(), v.encode()) == 0, (k, v)
+        libs.append((name, Lh))
     dt = {"bf16": (torch.bfloat16, 0), "fp16": (torch.float16, 1), "f32": (torch.float32, 2)}[a.dtype]
     dev = torch.device("cuda:0")
     for shp in a.shapes.split(","):
