@@ -7,10 +7,16 @@ resident in HBM: K1 per-token row-quant (pq_quant_rowwise) -> K3/K4 int8 MFMA GE
 epilogue (pq_qlinear_s8), weights pre-quantised per output channel (as a deployed qlinear holds them).
 Both launches go through the C-ABI of libpq_hip.so on torch's current stream, captured in a hipGraph.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): data-parallel over
-tokens — every rank runs the same step on its own 4096-token batch with replicated weights, no
-data-path collective (weak scaling).  `--mode tp` instead column-shards the weight (N/G output
-channels per rank) and all-gathers the transposed output shards with RCCL (BASELINE config 5 layout).
+Protocol: W untimed warm-up steps, then warm-up BY TIME (default 1.5 s of the same steps, untimed), then R = 20
+blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; per block the max over ranks; the reported step is the
+MEDIAN block (min / max alongside).  Per-kernel durations come from interleaved hipGraph replays of each kernel alone and of the
+compute step, and the script asserts GEMM + K1 <= 1.05 x step.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): north_star's split — the weight is column-sharded
+over the ranks (N/G output channels each), the activation replicated, and ONE RCCL all-gather of the bf16 output shards per step
+rebuilds y[M, N] (libpq_rccl.so: ncclAllGather + layout kernel); the whole job is ONE M x N x K qlinear (strong scaling).  The
+data-parallel figure (every rank its own batch, replicated weights, no collective) is reported under "dp"; `--mode dp` makes it the
+main line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (GEMM kernel vs the
 5.033 POPS dense int8 MFMA peak, timed live with HIP events) and `cpu_baseline` (the QSPEC pipeline
