@@ -446,11 +446,20 @@ def main():
         gather, info = None, {}
         if tp_mode:
             y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            rg = None
             if args.backend == "nccl" and not args.torch_gather:
-                from protoquant_amd.sharded import RcclColumnGather
-                rg = RcclColumnGather()
-                info = {"exchange": "libpq_rccl.so pq_allgather_cols (ncclAllGather + layout kernel)", "rccl_ranks": rg.comm_ranks()}
-
+                try:                                   # the native exchange; a failure to bootstrap it must not lose the measurement
+                    from protoquant_amd.sharded import RcclColumnGather
+                    rg = RcclColumnGather()
+                    info = {"exchange": "libpq_rccl.so pq_allgather_cols_v (ncclAllGather + layout kernel)", "rccl_ranks": rg.comm_ranks()}
+                except Exception as e:
+                    print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed's all-gather", file=sys.stderr)
+                    rg = None
+                ok = torch.tensor([1 if rg is not None else 0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank must take the same path
+                if int(ok.item()) == 0:
+                    rg = None
+            if rg is not None:
                 def gather():
                     rg.gather_into(y, y_full, N)
             else:

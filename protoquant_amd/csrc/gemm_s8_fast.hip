@@ -58,6 +58,8 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 // `make asm` + grep m0 confirms) — round 1 saved and restored it around every piece, 16 extra SALU per K-tile per wave.
 // hipcc does not count this load: the K-loop waits with explicit vmcnt.
 __device__ __forceinline__ void glds16_sbase(const int8_t* base, uint32_t voff, uint32_t lds_addr) {
+    // (cache-policy bits on this load — sc1 / sc0, which bypass the vector L1 — measured within 0.2 % of none on every tile kind:
+    // profiles/r02_ab_experiments.txt)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
@@ -87,7 +89,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // TN: columns (n) of the output tile, 256 or 128 (with TM = 128 only): a 128 x 128 tile for 1024-wide shards whose grid would
 // otherwise fill half the chip or need split-K.  It needs 32 KiB of DMA and 96 KiB of LDS fragment reads per 512
 // MFMA-cycles, so it runs LDS-read/ingest-bound — but with every CU busy and no slab traffic.
-template <int OUT, int ABL, int TM = 256, int TN = 256>   // ABL: compile-time ablation (0 = product)
+// LC (TM = 128, TN = 256 only): the loader / consumer wave split of the ring tile below applied to this kernel — waves 0-3 are
+// consumers with the 256-row kernel's wave tile (128 n x 64 m, four 16-MFMA quadrants, 2 x 2 waves over the 256 n x 128 m tile) and
+// issue no DMA; waves 4-7 are loaders that issue all 48 pieces of a K-tile (12 each) and do the vmcnt waits; both roles meet at
+// the same barriers.  The 8-wave form of this tile runs ~1900 cycles per K-tile against 1024 of MFMA because all 8 waves stall in
+// their DMA issues at the same point of the tile; here a SIMD's consumer never issues a DMA.  It also reads 96 instead of 160 KiB
+// of LDS fragments per K-tile (the wave tile is twice as tall).
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -121,9 +129,14 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr int SCALE_OFF = NBUF * BUFB;                                                 // ring (and, in a free slot, the epilogue staging) below, scales above
     __shared__ __attribute__((aligned(16))) uint8_t smem[SCALE_OFF + 2048];                // + 1 KiB row scales + 1 KiB column scales
 
+    static_assert(!LC || (TM == 128 && TN == 256), "loader / consumer split: 128 x 256 tile only");
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = w >> 2, wq = w & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LC && wave >= 4;
+    const int w = LC ? (wave & 3) : wave;               // index inside the role (issuer index for DMA pieces, consumer index for tiles)
+    constexpr int NWQ = LC ? 2 : 4;                      // consumer waves along m
+    constexpr int NISS = LC ? 4 : 8;                     // waves that issue DMA pieces
+    const int wp = w / NWQ, wq = w % NWQ;
 
     // ---- tile assignment: XCD remap, then grouped order (GM m-tiles per band) for L2 reuse
     // split-K (int32 output only): blocks [s*ntiles, (s+1)*ntiles) own K-slice s and write their exact partial
@@ -141,10 +154,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     static_assert(TM == 256 || TM == 128, "tile rows");
     static_assert(TN == 256 || (TN == 128 && TM == 128), "TN = 128 comes with TM = 128");
-    constexpr int PWH = TN / 4;           // P rows per wave per half-tile: 64 or 32
-    constexpr int PPW = TN / 128;         // DMA pieces per wave per P half-tile: 2 or 1 (a P half-tile is TN/2 rows)
-    constexpr int QW = TM / 8;            // Q rows per wave per half-tile: 32 or 16
-    constexpr int QPW = TM / 128;         // DMA pieces per wave per Q half-tile: 2 or 1 (a Q half-tile is TM/2 rows)
+    constexpr int PWH = TN / 4;                   // P rows per wave per half-tile: 64 or 32
+    constexpr int PPW = (TN / 16) / NISS;         // DMA pieces per issuing wave per P half-tile (a P half-tile is TN/2 rows = TN/16 pieces)
+    constexpr int QW = (TM / 2) / NWQ;            // Q rows per wave per half-tile: 32 or 16
+    constexpr int QPW = (TM / 16) / NISS;         // DMA pieces per issuing wave per Q half-tile (a Q half-tile is TM/2 rows)
     // ---- staging source offsets: wave w issues pieces (w*2+jj), jj = 0,1, of every half-tile.
     // LDS row r = w*16 + jj*8 + (lane>>3) of the half-tile; physical chunk lane&7.
     // P half h, LDS row r <-> n_local = (r/PWH)*2PWH + h*PWH + (r%PWH);  Q: m_local = (r/QW)*2QW + h*QW + (r%QW).
@@ -263,6 +276,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     auto mma = [&](acc_t (&c)[NPI][NQJ], v4i (&fp)[NPI][NKS], v4i (&fq)[NQJ][NKS], auto&& slot) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<NM>([&](auto xc) {
+            // MFMA order inside a quadrant: the P fragment is shared by NQJ consecutive MFMAs.  (Q-fragment-stationary and
+            // accumulator-stationary orders measured 0.7-1.3 % slower: profiles/r02_ab_experiments.txt)
             constexpr int x = decltype(xc)::value, ks = x / (NPI * NQJ), i = (x / NQJ) % NPI, j = x % NQJ;
             if (!no_mma) {
                 c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fp[i][ks], fq[j][ks], c[i][j], 0, 0, 0);
@@ -293,19 +308,20 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         const int nextoff = (slot + 1 == NBUF ? 0 : slot + 1) * BUFB;
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value, dma = decltype(has_dma)::value;
         constexpr int VMA = !next ? 0 : ((NBUF == 3 && next2) ? 2 * NDMA : NDMA);
-        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(VMA + PPW, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }   // Q1 of tile 0 visible
+        // (LC: the loaders do the vmcnt waits; a consumer only retires its own LDS reads before each barrier)
+        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(LC ? 63 : VMA + PPW, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }   // Q1 of tile 0 visible
         mma(acc[0][0], fPa, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (x < NQR) readQ_item(bufoff, 1, fQb, xc);
         });
-        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(VMA, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }         // P1 of tile 0 visible
+        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(LC ? 63 : VMA, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }         // P1 of tile 0 visible
         mma(acc[0][1], fPa, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
         });
         if constexpr (next) {
             // tile kt+1 must have landed; with a 3-deep ring tile kt+2 (NDMA pieces per wave) may stay in flight
-            if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   // lgkmcnt(0) only
+            if constexpr (no_vmwait || LC) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   // lgkmcnt(0) only
             else if constexpr (NBUF == 3 && next2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(NDMA, 0));
             else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
             if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         mma(acc[1][0], fPb, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
             if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(nextoff, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-            if constexpr (dma && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(slot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
+            if constexpr (dma && !LC && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(slot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
         });
         mma(acc[1][1], fPb, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     const bool scales_in_lds = (OUT == OUT_I32) ||
         ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
     if constexpr (OUT != OUT_I32) {
-        if (scales_in_lds && w < 2) {
+        if (scales_in_lds && w < 2 && (!LC || loader)) {
             const int base = w == 0 ? m0 : n0, lim = w == 0 ? M : N;
             int e0 = base + lane * 4;
             e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
@@ -337,15 +353,37 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             glds16_vaddr(src, smem_base + SCALE_OFF + w * 1024);     // (one more piece ahead of this wave's tile pieces: waited for with them)
         }
     }
-    stage_tile(0);
-    if (NT > 1) stage_tile(1);
-    if (NBUF == 3 && NT > 2) stage_tile(2);
-    // wait for the first half of tile 0 only (P0, Q0 — pieces are issued in need order P0 | Q0 | Q1 | P1): the rest of
-    // tile 0 and the other staged tiles stay in flight
-    const int vm_after = ((NT < NBUF ? NT : NBUF) - 1) * NDMA;
-    if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
-    else wait_vmcnt_lgkm0(vm_after + NDMA - PPW - QPW);
+    const int vm_after = ((NT < NBUF ? NT : NBUF) - 1) * NDMA;      // DMA pieces (per issuing wave) behind tile 0's
+    if (!LC || loader) {
+        stage_tile(0);
+        if (NT > 1) stage_tile(1);
+        if (NBUF == 3 && NT > 2) stage_tile(2);
+        // wait for the first half of tile 0 only (P0, Q0 — pieces are issued in need order P0 | Q0 | Q1 | P1): the rest of
+        // tile 0 and the other staged tiles stay in flight
+        if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+        else wait_vmcnt_lgkm0(vm_after + NDMA - PPW - QPW);
+    }
     __builtin_amdgcn_s_barrier();
+    if constexpr (LC) {
+        if (loader) {
+            // The loader's K-loop mirrors the consumers' barriers one for one.  Tile 0: Q1, then P1, each behind its wait;
+            // then per K-tile: wait until this wave's pieces of tile kt+1 have landed (tile kt+2 may stay in flight), the
+            // mid-tile barrier, and the 12 pieces of tile kt+3 into the slot tile kt vacates.
+            wait_vmcnt_lgkm0(vm_after + PPW); __builtin_amdgcn_s_barrier();
+            wait_vmcnt_lgkm0(vm_after); __builtin_amdgcn_s_barrier();
+            int lslot = 0;
+            for (int lk = 0; lk < NT; ++lk) {
+                if (lk + 1 < NT) {
+                    if (lk + 2 < NT) __builtin_amdgcn_s_waitcnt(waitcnt_imm(NDMA, 15));
+                    else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (lk + NBUF < NT) stage_tile(lslot);
+                lslot = (lslot + 1 == NBUF) ? 0 : lslot + 1;
+            }
+            return;
+        }
+    }
     stamp(1);
     readP(0, 0, fPa);
     readQ(0, 0, fQa);
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
         // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
         // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
-        constexpr int WREG = BUFB / 8;                                      // 8, 6 or 4 KiB
+        constexpr int WREG = BUFB / (LC ? 4 : 8);                           // 8, 6 or 4 KiB (LC: 12 KiB for each of the 4 consumers)
         const int last_slot = (NT - 1) % NBUF;
         const uint32_t sw_off = (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
         constexpr int NPT = 2 * NPI, NQT = 2 * NQJ;                         // column / row tiles of the wave block
@@ -473,11 +511,20 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
+bool g_sp128_lc = true;     // loader / consumer split of the 128 x 256 tile (pq_set_option("PQ_SP128_LC", "0") restores the 8-wave form)
+void set_sp128_lc(bool v) { g_sp128_lc = v; }
+
 template <int OUT, int TM, int TN>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
                       int64_t M, int64_t N, int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
+    if constexpr (TM == 128 && TN == 256) {
+        if (g_sp128_lc) {
+            gemm_s8_sp256<OUT, 0, TM, TN, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+            return;
+        }
+    }
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && TM == 256 && TN == 256) {
         switch (gemm_debug_flags()) {

@@ -26,6 +26,7 @@ void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
 void set_ring_lc(bool);
+void set_sp128_lc(bool);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -142,7 +143,7 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
 // second launch of 128(m) x 256(n) tiles instead — twice the blocks, each ~0.65 of a full tile's time (measured) — so
 // e.g. 344 tiles cost 1 + 0.65 rounds instead of 2.  Both launches are plain sub-problems (pointer offsets), results are
 // unchanged bit for bit.  Returns the split axis (0 none, 1 along N, 2 along M) and the extent of the leading part.
-constexpr double kHalfTileCost = 0.65, kSecondLaunchCost = 0.06;
+constexpr double kHalfTileCost = 0.58, kSecondLaunchCost = 0.06;   // (round 2: the loader/consumer form of the 128-row tile: 29 vs 51 us per tile at K = 4096)
 
 int tail_split_plan(int64_t M, int64_t N, int64_t* lead) {
     if (options().no_tailsplit) return 0;
@@ -205,6 +206,7 @@ int32_t pq_set_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));

@@ -30,12 +30,34 @@ def test_headline_json_contract():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TOP/s" and r["peak"] == 5033.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.2 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 6e7)
+    # the line is reproducible from itself: GEMM + K1 (gap-free replays) fit the step, the timed region is repeated blocks
+    assert d["timings_consistent"] is True and d["config"]["repeats"] >= 20
+    assert r["avg_kernel_us"] + d["quant_pass"]["avg_kernel_us"] <= 1.05 * d["compute_step_us"]
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "TOPS" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the stated baseline is the best of the thread sweep, never below the 1-thread figure (round 1's was)
+    assert c["value"] >= c["value_1_thread"] and c["value"] == max(c["thread_sweep_tops_median"].values())
+    assert set(c["stage_ms_min"]) == {"quantize", "int_mm", "epilogue"} and "host_cpu" in c
+
+
+def test_tp_dry_run_two_ranks_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU over gloo: the N > 1 line is
+    north_star's split (column-sharded weight + all-gather, strong scaling) with the dp figure as an extra key."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "3",
+                        "--warmup-seconds", "0.2", "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"].startswith("tp2") and d["config"]["rccl_ranks"] == 2
+    assert d["dp"]["scaling"] == "weak" and d["dp"]["value"] > 0 and d["cpu_baseline"] is None
 
 
 @pytest.mark.parametrize("args,unit", [(("--workload", "mlp", "--steps", "20", "--warmup", "3"), "TOPS"),
-                                       (("--workload", "llama8b", "--tokens", "16", "--steps", "3", "--norms"), "TB/s")])
+                                       (("--workload", "llama8b", "--tokens", "16", "--steps", "3", "--norms"), "TB/s"),
+                                       (("--workload", "llama8b", "--layers", "2", "--steps", "3"), "TOPS")])
 def test_optional_workloads_run(args, unit):
     d = _run(*args)
     assert d["unit"] == unit and d["value"] > 0 and "roofline" in d and "workload" in d["config"]
