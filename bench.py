@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-consistency-check", action="store_true")
     ap.add_argument("--layers", type=int, default=32, help="llama8b workload: decoder layers (32 = the model)")
     ap.add_argument("--no-layer-fusion", action="store_true", help="llama8b workload: skip fuse_llama_layers (stock norms, separate q/k/v GEMMs)")
-    ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b", "llama8b-linears"], default="qlinear",
+    ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b", "llama8b-linears", "llama70b-shard"], default="qlinear",
                     help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -378,11 +378,74 @@ def run_llama8b(args):
                       "cpu_baseline": None}), flush=True)
 
 
+def run_llama70b_shard(args):
+    """BASELINE configs[4], ONE rank's compute at the real shapes: Llama-3-70B (hidden 8192, intermediate 28672, 80 layers, 64 heads /
+    8 KV heads, vocab 128256) with every linear's int8 weight column-sharded over G = 8 GPUs, M = 4096 tokens (seq is not stated in
+    BASELINE.json: assumed 4096 as in configs[3]).  This process plays rank 0 on one GPU: per layer the fused q/k/v shard
+    (N = 10240 / 8 = 1280), the o shard (1024), the fused gate+up shard (2 x 3584) and the down shard (1024, K = 28672), each with
+    its activation quantisation on the replicated input (RMSNorm fused for q/k/v and gate/up; silu*mul needs the GATHERED gate/up in this
+    configuration, so down's input is quantised by plain K1), plus the lm_head shard (16032).  No collective runs (one GPU): the
+    exchange is priced from the bytes with the xGMI link model of DESIGN.md section 6, and stated as modelled."""
+    import protoquant_amd as pq
+    from protoquant_amd.qtensor import QTensor
+    dev = torch.device("cuda", 0)
+    G, M, H, I, V, L = 8, args.tokens, 8192, 28672, 128256, args.layers if args.layers != 32 else 80
+    KVD = 1024
+
+    def mkq(n, k):
+        wq = (torch.randn(n, k, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
+        return pq.qlinear.from_qtensor(QTensor(wq, torch.rand(n, device=dev) * 1e-3 + 1e-4, 1, torch.bfloat16, wq.shape))
+    n_qkv, n_o, n_gu, n_down, n_head = (H + 2 * KVD) // G, H // G, 2 * I // G, H // G, V // G
+    # two distinct layers' weights alternate (80 x 1.1 GB of shards would fit, but two already defeat any cache reuse between layers)
+    layers = [(mkq(n_qkv, H), mkq(n_o, H), mkq(n_gu, H), mkq(n_down, I)) for _ in range(2)]
+    head = mkq(n_head, H)
+    x_h = torch.randn(M, H, device=dev).to(torch.bfloat16)          # stands for a gathered hidden state
+    x_i = torch.randn(M, I, device=dev).to(torch.bfloat16)          # stands for the gathered silu(g) * u
+    norm_w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+
+    def fwd():
+        for l in range(L):
+            qkv, o, gu, down = layers[l & 1]
+            qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
+            o(x_h)
+            gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
+            down(x_i)
+        return head(x_h)
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(max(3, min(args.steps, 10))):
+        t0 = time.perf_counter(); fwd(); torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    ops = L * 2.0 * M * (n_qkv * H + n_o * H + n_gu * H + n_down * I) + 2.0 * M * n_head * H
+    # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
+    gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
+    t_gather = gathered * (G - 1) / G / (7 * 153e9)
+    print(json.dumps({"metric": "int8 TOPS per GPU, Llama-3-70B column-sharded over 8 GPUs: one rank's linears at M=4096 (exchange modelled)",
+                      "value": round(ops / dt / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(ts), "warmup": 2, "ms_per_step": round(dt * 1e3, 3),
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+                      "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
+                                             f"4096x{n_o}x8192 (o), 4096x{n_gu}x8192 (fused gate+up), 4096x{n_down}x28672 (down), 4096x{n_head}x8192 (lm_head) (BASELINE configs[4])",
+                                 "int8_ops_per_rank": ops, "gathered_bytes_per_pass": gathered,
+                                 "modelled_allgather_ms": round(t_gather * 1e3, 2),
+                                 "model": "all-gather after dequant of every linear's bf16 output; a rank receives 7/8 of it over 7 xGMI links x 153 GB/s (fully connected, direct); NOT measured"},
+                      "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                                   "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
+                                   "note": "one rank's compute only: every activation quantisation (RMSNorm fused for q/k/v and gate/up) + the shard GEMMs"},
+                      "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
     if args.workload == "llama8b":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"
         return run_llama8b(args) if args.tokens > 512 else run_llama8b_linears(args)
+    if args.workload == "llama70b-shard":
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama70b-shard plays one rank on one GPU"
+        return run_llama70b_shard(args)
     if args.workload == "llama8b-linears":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b-linears is a 1-GPU measurement"
         return run_llama8b_linears(args)

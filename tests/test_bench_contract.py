@@ -57,7 +57,8 @@ def test_tp_dry_run_two_ranks_one_gpu():
 
 @pytest.mark.parametrize("args,unit", [(("--workload", "mlp", "--steps", "20", "--warmup", "3"), "TOPS"),
                                        (("--workload", "llama8b", "--tokens", "16", "--steps", "3", "--norms"), "TB/s"),
-                                       (("--workload", "llama8b", "--layers", "2", "--steps", "3"), "TOPS")])
+                                       (("--workload", "llama8b", "--layers", "2", "--steps", "3"), "TOPS"),
+                                       (("--workload", "llama70b-shard", "--layers", "2", "--steps", "3"), "TOPS")])
 def test_optional_workloads_run(args, unit):
     d = _run(*args)
     assert d["unit"] == unit and d["value"] > 0 and "roofline" in d and "workload" in d["config"]
