@@ -33,12 +33,13 @@ while time.time() - t0 < budget:
         yv = ybig[:, off_y:off_y + N]                  # the output as a window of a wider matrix: ld > N, maybe unaligned
         pq.qlinear_s8(a, xs, b, ws, bias, dt, out=yv)
         y = yv.contiguous(); acc = pq.int_mm(a, b)
+        yt = pq.qlinear_s8_t(a, xs, b, ws, bias, dt)            # the transposed-output form must hold the same bits
         if pad_y + off_y:
             outside = torch.cat([ybig[:, :off_y], ybig[:, off_y + N:]], dim=1)
             if not bool((outside == 7.0).all()):
                 bad += 1; print(f"WROTE OUTSIDE variant={v or 'auto'} M={M} N={N} K={K} pad_y={pad_y} off_y={off_y}")
         iv = torch.int32 if dt == torch.float32 else torch.int16
-        d = int((y.view(iv) != ref_y.view(iv)).sum()) + int((acc != ref_acc).sum())
+        d = int((y.view(iv) != ref_y.view(iv)).sum()) + int((acc != ref_acc).sum()) + int((yt.t().contiguous().view(iv) != ref_y.view(iv)).sum())
         if d:
             bad += 1
             print(f"MISMATCH variant={v or 'auto'} M={M} N={N} K={K} pads=({pad_a},{pad_b}) dtype={dt} bias={bias is not None}: {d} elements")
