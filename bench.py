@@ -616,6 +616,19 @@ def main():
         tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
     med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
     t_gemm, t_k1, t_stepc = med(tk3), med(tk1), med(tst)
+    # the same K1 kernel on a 4x taller activation (16384 rows): at the headline size ~1.5 us of launch ramp + tail sit on an
+    # 8-us transfer; the streaming rate of the kernel itself shows on the larger input
+    k1_big = None
+    if not tp:
+        Mb = 4 * M
+        xb_ = torch.randn(Mb, K, device=dev).to(torch.bfloat16)
+        qb_ = torch.empty((Mb, K), dtype=torch.int8, device=dev); sb_ = torch.empty((Mb,), dtype=torch.float32, device=dev)
+        gb_ = graph_of(lambda: L.check(lib.pq_quant_rowwise(xb_.data_ptr(), 0, Mb, K, K, qb_.data_ptr(), K, sb_.data_ptr(), st()), "pq_quant_rowwise"), 10)
+        gb_.replay(); torch.cuda.synchronize()
+        tb = med([ev_us(gb_, 10) for _ in range(15)])
+        k1_big = {"rows": Mb, "cols": K, "avg_kernel_us": round(tb, 2), "achieved": round((3 * Mb * K + 4 * Mb) / tb / 1e3, 1), "unit": "GB/s",
+                  "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4)}
+        del xb_, qb_, sb_
     if tp:
         fence()
     consistent = (t_gemm + t_k1) <= 1.05 * t_stepc
@@ -628,7 +641,7 @@ def main():
     gemm_bytes = M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local)
     gemm_ops = 2.0 * M * n_local * K
     variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
-    kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<TM=128> (K3+K4)", "ring128": "gemm_s8_ring128 (K3+K4)",
+    kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
              "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
     if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
         kname += " split-K + splitk_reduce_epilogue"
@@ -652,7 +665,7 @@ def main():
                      "in_step_us": round(t_stepc - t_k1, 2), "traffic": None, "algorithmic_bytes": gemm_bytes},
         "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1),
                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4),
-                       "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes},
+                       "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes, "same_kernel_4x_rows": k1_big},
         "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
     }
     tj = os.path.join(ROOT, "profiles", "traffic.json")
