@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--warmup-seconds", type=float, default=1.5, help="untimed warm-up by time after the --warmup steps")
     ap.add_argument("--torch-gather", action="store_true", help="tp: exchange through torch.distributed instead of libpq_rccl.so")
     ap.add_argument("--no-dp-leg", action="store_true", help="tp: skip the extra dp figure")
+    ap.add_argument("--tp-transposed-leg", action="store_true", help="tp (RCCL): also time the transposed-shard form (pq_qlinear_s8_t + contiguous all-gather)")
     ap.add_argument("--no-consistency-check", action="store_true")
     ap.add_argument("--layers", type=int, default=32, help="llama8b workload: decoder layers (32 = the model)")
     ap.add_argument("--no-layer-fusion", action="store_true", help="llama8b workload: skip fuse_llama_layers (stock norms, separate q/k/v GEMMs)")
@@ -676,6 +677,37 @@ def main():
             out["roofline"]["traffic_source"] = tr.get("source")
         except Exception:
             pass
+    if tp and args.tp_transposed_leg and xinfo.get("exchange", "").startswith("libpq_rccl"):
+        # extra key: the same split with TRANSPOSED shards (pq_qlinear_s8_t -> y^T[n0:n1, :], one contiguous all-gather into
+        # y^T[N, M], no staging buffer and no layout kernel; the result is y as a column-major view with the same bits)
+        try:
+            from protoquant_amd.sharded import RcclColumnGather as _RG
+            rg_t = _RG()
+            x_, xq_, xs_, y_, wq_, ws_, _w = _keep
+            yt_loc = torch.empty((n_local, M), dtype=torch.bfloat16, device=dev)
+            yt_full = torch.empty((N, M), dtype=torch.bfloat16, device=dev)
+            wb_t = lib.pq_qlinear_t_workspace_bytes(M, n_local, K)
+            wsp_t = torch.empty((max(wb_t, 16),), dtype=torch.uint8, device=dev)
+
+            def k3t():
+                L.check(lib.pq_qlinear_s8_t(xq_.data_ptr(), K, xs_.data_ptr(), wq_.data_ptr(), K, ws_.data_ptr(), None, yt_loc.data_ptr(), M, 0,
+                                            M, n_local, K, wsp_t.data_ptr() if wb_t else None, wb_t, st()), "pq_qlinear_s8_t")
+            gt = graph_of(lambda: (k1(), k3t()), 1)
+            for _ in range(10):
+                gt.replay(); rg_t.gather_t(yt_loc, N, out=yt_full)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                gt.replay(); rg_t.gather_t(yt_loc, N, out=yt_full)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t0
+            tt = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out["tp_transposed"] = {"value": round(2.0 * M * N * K * 200 / float(tt.item()) / 1e12, 2), "unit": "TOPS", "ms_per_step": round(float(tt.item()) / 200 * 1e3, 5),
+                                    "exchange": "pq_qlinear_s8_t + pq_allgather_rows_t (contiguous ncclAllGather, no layout kernel); y returned as the column-major view y^T.t()"}
+            rg_t.close()
+        except Exception as e:      # an extra figure must never lose the main line
+            print(f"[bench] transposed-shard leg failed: {e}", file=sys.stderr)
     if tp and not args.no_dp_leg:
         # extra key: the same ranks as independent replicas over tokens (weak scaling, no collective), short
         k1d, k3d, _g, _nl, _i, _keep2 = build_step(False)
