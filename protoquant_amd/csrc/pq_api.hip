@@ -27,6 +27,8 @@ void set_skinny_rb(int);
 void set_k1_rpw(int);
 void set_ring_lc(bool);
 void set_sp128_lc(bool);
+void set_silu_tpr(int);
+void set_rms_wave_max(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 }  // namespace pq
 
@@ -206,6 +208,8 @@ int32_t pq_set_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : 512);
+    else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));

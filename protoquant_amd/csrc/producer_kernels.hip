@@ -201,12 +201,13 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
                                                   int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     ab = wave_max_u32(ab);
-    __shared__ uint32_t part[256 / kWave];
+    constexpr int NW = (TPR > 256 ? TPR : 256) / kWave;      // waves of the block (a row group wider than a wave is the whole block)
+    __shared__ uint32_t part[NW];
     if constexpr (TPR > kWave) {
         if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
+        for (int w = 0; w < NW; ++w) ab = part[w] > ab ? part[w] : ab;
     }
     const bool has_nan = amax_bits_has_nan<DT>(ab);
     float amax = amax_bits_to_f32<DT>(ab);
@@ -225,7 +226,7 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
             if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
             __syncthreads();
 #pragma unroll
-            for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
+            for (int w = 0; w < NW; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
         }
     }
     const float s = scale_of(amax);
@@ -260,13 +261,16 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
     }
 }
 
+// TPR = 512 (a 512-thread block per row, wide rows): round 1 held such rows with 256 threads x 8 vectors of g and of u —
+// 143 VGPRs, 3 waves per SIMD in a kernel that is VALU-bound before it is HBM-bound; 512 threads x 3-4 vectors need < 100.
 template <int DT, int VPT, int TPR, bool WRITE_H>
-__global__ __launch_bounds__(256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
+__global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
                                                           const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
                                                           int nvec, int8_t* __restrict__ q, int64_t ldq,
                                                           float* __restrict__ scale, uint8_t* __restrict__ h_out,
                                                           int64_t ldh_bytes) {
-    constexpr int RPB = 256 / TPR;
+    constexpr int BS = TPR > 256 ? TPR : 256;
+    constexpr int RPB = BS / TPR;
     const int t = threadIdx.x % TPR;
     int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
     const bool active = row < rows;
@@ -508,16 +512,26 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_generic(const void* __restr
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
+int g_rms_wave_max = 64 * 8;     // widest row (in 16-byte vectors) of the wave-per-row RMSNorm layout (pq_set_option("PQ_RMS_WAVE_MAX"))
+void set_rms_wave_max(int v) { g_rms_wave_max = v < 0 ? 0 : (v > 512 ? 512 : v); }
+int g_silu_tpr = 0;       // 0 auto; 256 forces the 256-thread layout on wide rows (pq_set_option("PQ_SILU_TPR", "256"))
+void set_silu_tpr(int v) { g_silu_tpr = v; }
+
 template <int DT, int TPR, bool WRITE_H>
 static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const uint8_t* u, int64_t ldu_b, int64_t rows, int nvec,
                                 int8_t* q, int64_t ldq, float* scale, uint8_t* h, int64_t ldh_b, hipStream_t st) {
-    constexpr int RPB = 256 / TPR;
-    const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
+    constexpr int BS = TPR > 256 ? TPR : 256, RPB = BS / TPR;
+    const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(BS);
     switch (vpt) {
         case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
         case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 3:
+            if constexpr (TPR == 512) silu_mul_quant_vec<DT, 3, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            break;
         case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
-        case 8: silu_mul_quant_vec<DT, 8, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 8:
+            if constexpr (TPR != 512) silu_mul_quant_vec<DT, 8, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            break;
         default:
             if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
             break;
@@ -545,6 +559,13 @@ void silu_mul_quant_dispatch(const void* g, int64_t ldg, const void* u, int64_t 
         const int vpt = pow2((nvec + 63) / 64);
         if (h_out) launch_silu_mul_vec<DT, 64, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
         else launch_silu_mul_vec<DT, 64, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
+    } else if (nvec > 1024 && nvec <= 1536 && g_silu_tpr != 256) {
+        // rows of 1025..1536 vectors (e.g. 11008 columns): 512 threads x 3 vectors fill 90 % of their slots where 256 threads x 8
+        // fill 67 % (the kernel is VALU-bound, idle slots are idle lanes): 2048 x 11008 30.4 -> 28.1 us.  At 1537..2048 vectors
+        // (14336, 16384 columns) both layouts have the same slots and measured the same (profiles/r02_k1s_threads_per_row.txt).
+        const int vpt = (nvec + 511) / 512;        // 3
+        if (h_out) launch_silu_mul_vec<DT, 512, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
+        else launch_silu_mul_vec<DT, 512, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
     } else {
         const int vpt = pow2((nvec + 255) / 256);
         if (h_out) launch_silu_mul_vec<DT, 256, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
@@ -568,7 +589,7 @@ void rmsnorm_quant_dispatch(const void* x, int64_t ldx, const void* wgt, float e
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(wgt);
     uint8_t* hb = reinterpret_cast<uint8_t*>(h_out);
     const int64_t kb = Elem<DT>::kBytes;
-    if (nvec <= 64 * 8) {                 // one wave per row (rmsnorm_quant_wave): VPT in {4, 8} keeps i & 3 meaningful
+    if (nvec <= g_rms_wave_max) {         // one wave per row (rmsnorm_quant_wave): VPT in {4, 8} keeps i & 3 meaningful
         const dim3 wgrid((unsigned)((rows + 3) / 4));
 #define PQ_RMSW_LAUNCH(V)                                                                                                                 \
     do {                                                                                                                              \
