@@ -512,8 +512,12 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_generic(const void* __restr
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-int g_rms_wave_max = 64 * 8;     // widest row (in 16-byte vectors) of the wave-per-row RMSNorm layout (pq_set_option("PQ_RMS_WAVE_MAX"))
-void set_rms_wave_max(int v) { g_rms_wave_max = v < 0 ? 0 : (v > 512 ? 512 : v); }
+// widest row (in 16-byte vectors) of the wave-per-row RMSNorm layout (pq_set_option("PQ_RMS_WAVE_MAX"), 0..512).  Round 1 used it up to
+// 512 vectors (a 4096-wide bf16 hidden state): 118 VGPRs, 4 waves per SIMD.  Measured in round 2 (profiles/r02_k1n_layout.txt): at 512
+// vectors the 256-thread block per row (2 vectors per thread, ~44 VGPRs) is 10 % faster at 4096 rows (15.7 -> 14.2 us) and equal at 16384;
+// at 256 vectors the wave layout wins (8.7 vs 9.6 us).  Same bits either way (QSPEC N1-N3 pins the order of the sum).
+int g_rms_wave_max = 256;
+void set_rms_wave_max(int v) { g_rms_wave_max = v < 0 ? 256 : (v > 512 ? 512 : v); }
 int g_silu_tpr = 0;       // 0 auto; 256 forces the 256-thread layout on wide rows (pq_set_option("PQ_SILU_TPR", "256"))
 void set_silu_tpr(int v) { g_silu_tpr = v; }
 
