@@ -40,7 +40,7 @@ def pq_opt():
         _lib.set_option(name, value)
     yield set_
     for n in touched:
-        _lib.set_option(n, "")
+        _lib.set_option(n, "")          # "" = the default of every switch
 
 
 def load_golden(path):

@@ -762,6 +762,20 @@ def test_rmsnorm_quant_vs_oracle(pq, code, rows, cols):
         same(qt.int_data, want_q, "q (strided)"); same(qt.scale, want_s, "scale (strided)")
 
 
+@pytest.mark.parametrize("wave_max", ["512", "0"])
+@pytest.mark.parametrize("code,cols", [(0, 4096), (0, 3072), (1, 2304), (2, 2048), (2, 1100 * 4 // 4 * 4)])
+def test_rmsnorm_both_layouts_same_bits(pq, pq_opt, wave_max, code, cols):
+    """The wave-per-row layout (forced up to 512 vectors per row: round 1's choice) and the 256-thread-block layout (forced everywhere)
+    both reproduce the oracle: QSPEC N1-N3 pins the order of the sum of squares, so the layout cannot change a bit."""
+    pq_opt("PQ_RMS_WAVE_MAX", wave_max)
+    rng = np.random.default_rng(cols + code)
+    x = Q.from_f32((rng.standard_normal((70, cols)) * rng.uniform(0.01, 50.0, (70, 1))).astype(np.float32), code)
+    w = Q.from_f32((1.0 + 0.3 * rng.standard_normal(cols)).astype(np.float32), code)
+    want_q, want_s, want_h, _ = C.rmsnorm_quant_rowwise(x, w, 1e-5, code)
+    qt, h = pq.rmsnorm_quantize(to_gpu(x, code), to_gpu(w, code), 1e-5, return_h=True)
+    same(qt.int_data, want_q, "q"); same(qt.scale, want_s, "scale"); _same_h(h, want_h, code, "h")
+
+
 @pytest.mark.parametrize("cols", [1025, 2043, 4102])
 def test_rmsnorm_fp16_rounds_to_f32_before_fp16(pq, cols):
     """QSPEC N5 rounds x*rs to binary32 and THEN to the storage dtype.  hipcc used to fold the multiply and the fp16 conversion
