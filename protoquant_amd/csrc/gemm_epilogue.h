@@ -156,7 +156,7 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
                 const int r = it * RPI + lrow;                                  // staged row of this lane
                 const v4u v = *reinterpret_cast<const v4u*>(smem + rbase + it * RPI * RBY + (((uint32_t)(ch ^ (r & KM))) << 4));
                 uint8_t* rowp = y_blk + (int64_t)(qp * QT_PASS * 16 + it * RPI) * ldy_bytes + pp * RBY;   // wave-uniform
-                *reinterpret_cast<v4u*>(rowp + vlane) = v;
+                store_wt_b128(rowp + vlane, v);                                  // write-through (pq_common.h)
             }
         }
     }

@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const int32_t* __r
     }
     const bool vec_st = full && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
     if (vec_st) {
-        if constexpr (sizeof(O) == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
-        else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+        if constexpr (sizeof(O) == 2) store_wt_b64(dst, *reinterpret_cast<const v2u*>(o));
+        else store_wt_b128(dst, *reinterpret_cast<const v4u*>(o));
     } else {
         for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = o[r];
     }

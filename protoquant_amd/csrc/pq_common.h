@@ -16,6 +16,21 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------- write-through global stores
+// Output streams (codes, dequantised tiles, y) are stored with the sc1 cache policy: the line is written through to the memory side
+// and dropped from the XCD's L2 instead of staying there dirty.  A kernel that leaves B dirty bytes in L2 pays ~B / 6 TB/s at its
+// end for the write-back (MI355X_MICROARCH.md, price-list row "boundary"): measured on this path, K1 at 4096 x 4096 9.3 -> 6.4 us
+// (16 MB of codes), the 4096^3 GEMM 50.9 -> 49.7 us (32 MB of y), the qlinear step 61.4 -> 59.6 us — same bits
+// (profiles/r02_write_through_stores.txt).  The next kernel reads these buffers from the Infinity Cache either way (the XCDs' L2s are
+// not coherent, and the consumer's tiles rarely sit on the producer's XCD).  Non-temporal stores (nt) were tried too: K1 alone is as
+// fast, but the consumer then misses the Infinity Cache as well and the step gets slower.
+// hipcc does not count an asm store in its vmcnt bookkeeping; that only makes its own counted waits stricter (vmcnt retires in order).
+__device__ __forceinline__ void store_wt_b128(void* p, const v4u& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");   // (s_nop 1: >64-bit store data hazard)
+}
+__device__ __forceinline__ void store_wt_b64(void* p, const v2u& v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_wt_b32(void* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+
 // ---------------------------------------------------------------- element types
 // DT: 0 bf16, 1 fp16 (both stored as 16-bit patterns), 2 f32.
 template <int DT> struct Elem;

@@ -233,9 +233,9 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
     if (!active) return;
     if (t == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
-    auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
-        if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
-        else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
+    auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {          // write-through (pq_common.h)
+        if constexpr (EPV == 8) store_wt_b64(qr + (int64_t)idx * 8, v2u{pk[0], pk[1]});
+        else store_wt_b32(qr + (int64_t)idx * 4, pk[0]);
     };
     if (!has_nan && scale_fast_ok(s)) {
         const float r = 1.0f / s;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(cons
             hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
             ab = vec_amax_bits<DT>(hv[i], ab);
             if constexpr (WRITE_H) {
-                if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+                if (active && idx < nvec) store_wt_b128(h_out + row * ldh_bytes + (int64_t)idx * 16, hv[i]);
             }
         }
     };
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_vec(const uint8_t* __restri
         ab = vec_amax_bits<DT>(hv[i], ab);
         if constexpr (WRITE_H) {
             const int idx = i * 256 + t;
-            if (idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+            if (idx < nvec) store_wt_b128(h_out + row * ldh_bytes + (int64_t)idx * 16, hv[i]);
         }
     }
     reduce_and_encode<DT, VPT, 256>(hv, ab, t, nvec, true, row, q, ldq, scale);
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_wave(const uint8_t* __restr
         ab = vec_amax_bits<DT>(hv[i], ab);
         if constexpr (WRITE_H) {
             const int idx = i * 64 + t;
-            if (active && idx < nvec) *reinterpret_cast<v4u*>(h_out + row * ldh_bytes + (int64_t)idx * 16) = hv[i];
+            if (active && idx < nvec) store_wt_b128(h_out + row * ldh_bytes + (int64_t)idx * 16, hv[i]);
         }
     }
     reduce_and_encode<DT, VPT, 64>(hv, ab, t, nvec, active, row, q, ldq, scale);

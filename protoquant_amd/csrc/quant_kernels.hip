@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
         if (t == 0) scale[row] = s;
         int8_t* qr = q + row * ldq;
         auto store_vec = [&](int idx, const uint32_t (&pk)[EPV / 4]) {
-            if constexpr (EPV == 8) *reinterpret_cast<v2u*>(qr + (int64_t)idx * 8) = v2u{pk[0], pk[1]};
-            else *reinterpret_cast<uint32_t*>(qr + (int64_t)idx * 4) = pk[0];
+            if constexpr (EPV == 8) store_wt_b64(qr + (int64_t)idx * 8, v2u{pk[0], pk[1]});
+            else store_wt_b32(qr + (int64_t)idx * 4, pk[0]);
         };
         if (!has_nan && scale_fast_ok(s)) {       // the hot path: no division per element, results identical to x / s
             const float r = 1.0f / s;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
             }
             if (live && rr < r1) {
                 int8_t* o = q + rr * ldq + cv * EPV;
-                if constexpr (EPV == 8) *reinterpret_cast<v2u*>(o) = v2u{pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])};
-                else if constexpr (EPV == 4) *reinterpret_cast<uint32_t*>(o) = pack4(c[0], c[1], c[2], c[3]);
+                if constexpr (EPV == 8) store_wt_b64(o, v2u{pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])});
+                else if constexpr (EPV == 4) store_wt_b32(o, pack4(c[0], c[1], c[2], c[3]));
                 else *o = (int8_t)c[0];
             }
         }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
             const int code = (int)(int8_t)((raw[j >> 2] >> (8 * (j & 3))) & 0xFF);
             res[j] = Elem<ODT>::from_f32((float)code * scv[j]);
         }
-        *reinterpret_cast<v4u*>(o) = *reinterpret_cast<const v4u*>(res);
+        store_wt_b128(o, *reinterpret_cast<const v4u*>(res));
     } else {
         const float sc = axis == 0 ? scale[cvr] : scale[r];
         *o = Elem<ODT>::from_f32((float)(*p) * sc);
