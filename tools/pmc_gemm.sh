@@ -22,7 +22,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][:60]
+        k = row["Kernel_Name"].split("(")[0][:60] + "  grid=" + row["Grid_Size"]     # (bench.py also runs K1 on 4x the rows: keep the launches apart)
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     if "at::native" in k: continue
