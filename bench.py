@@ -61,6 +61,7 @@ def parse():
                     help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-context", action="store_true", help="skip the stock torch-ROCm legs on this GPU (torch._int_mm pipeline, bf16 linear)")
     ap.add_argument("--tokens", type=int, default=4096, help="llama8b workload: tokens per pass (4096 = BASELINE configs[3] prefill; <= 512 = decode-like, replayed from a hipGraph)")
     ap.add_argument("--norms", action="store_true", help="llama8b workload: also run the two RMSNorms of every layer, fused into the activation quantisation (rmsnorm_quantize)")
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
@@ -143,6 +144,52 @@ def cpu_baseline(M, N, K, budget_s=25.0):
             "thread_sweep_tops_median": {str(t): rows[t]["tops_median"] for t in rows},
             "thread_sweep_ms_median": {str(t): rows[t]["ms_median"] for t in rows},
             "value_1_thread": rows[1]["tops_median"] if 1 in rows else None}
+
+
+def gpu_context(x, wq, ws, y_ref, med_of):
+    """Context, not the contract's baseline: the SAME qlinear written with stock torch-ROCm ops around `torch._int_mm` on THIS GPU — what
+    the reference's Python would execute on an MI355X (hipBLASLt int8 GEMM with int32 output, eager elementwise kernels around it) —
+    plus the int8 GEMM alone and the un-quantised bf16 linear.  hipGraph replays (no host gaps), HIP events, median.  The eager pipeline's
+    result is compared with the library's y (QSPEC written in torch ops; see the note on torch-ROCm's division below)."""
+    wt = wq.t()
+
+    def pipeline():
+        xf = x.float()
+        amax = xf.abs().amax(dim=1, keepdim=True)
+        s = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax))
+        xq = torch.round(xf / s).clamp_(-127, 127).to(torch.int8)
+        acc = torch._int_mm(xq, wt)
+        return ((acc.float() * s) * ws).to(torch.bfloat16)
+    out = {}
+    try:
+        yp = pipeline()
+        # torch-ROCm's elementwise float division on the GPU is not the correctly rounded one (a few per cent of the row scales differ in
+        # the last bit from the CPU's and from this library's, which matches the CPU bit for bit), so a small share of outputs differs
+        out["outputs_differing_from_library"] = int((yp.view(torch.int16) != y_ref.view(torch.int16)).sum().item())
+        out["outputs"] = int(yp.numel())
+        out["max_abs_diff"] = float((yp.float() - y_ref.float()).abs().max().item())
+        w_bf16 = (wq.float() * ws[:, None]).to(torch.bfloat16)
+        xq0 = torch.round(x.float()).clamp_(-127, 127).to(torch.int8)
+        legs = {"torch_rocm_int8_pipeline_us": pipeline, "torch_int_mm_alone_us": lambda: torch._int_mm(xq0, wt),
+                "torch_bf16_linear_us": lambda: torch.nn.functional.linear(x, w_bf16)}
+        n = 5
+        graphs = {k: graph_of(f, n) for k, f in legs.items()}
+        for g in graphs.values():
+            g.replay()
+        torch.cuda.synchronize()
+        ts = {k: [] for k in legs}
+        for _ in range(9):
+            for k, g in graphs.items():
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); g.replay(); b.record(); b.synchronize()
+                ts[k].append(a.elapsed_time(b) * 1e3 / n)
+        for k, v in ts.items():
+            out[k] = round(med_of(v), 2)
+        out["what"] = ("stock torch-ROCm ops on this GPU, hipGraph replays: the QSPEC pipeline around torch._int_mm (hipBLASLt int8, int32 out) = what the "
+                       "reference's Python would run here; that GEMM alone; the bf16 linear the int8 path replaces")
+    except Exception as e:      # context must never lose the main line
+        out["error"] = str(e)[:300]
+    return out
 
 
 def run_mlp(args):
@@ -617,24 +664,45 @@ def main():
         tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
     med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
     t_gemm, t_k1, t_stepc = med(tk3), med(tk1), med(tst)
-    # the same K1 kernel on a 4x taller activation (16384 rows): at the headline size ~1.5 us of launch ramp + tail sit on an
-    # 8-us transfer; the streaming rate of the kernel itself shows on the larger input
+    # K1 against HBM, not against the caches: replayed on ONE input, K1's 32-MB read set is served by the L2s (each XCD re-reads
+    # the same eighth of x every launch, and write-through stores leave nothing dirty to evict it) and the 256-MB Infinity Cache —
+    # 6.3-6.6 us, "0.95 of 8 TB/s", a cache figure.  The roofline entry therefore rotates over enough distinct input / output
+    # pairs (> 600 MB in total) that every launch reads from and writes to HBM; the cache-resident replay is reported beside it.
+    x_, _xq, _xs, _y, _wq, _ws, _w = _keep
+    n_rot = max(2, -(-600 * 2**20 // (3 * M * K)))
+    rot = [(torch.randn(M, K, device=dev).to(torch.bfloat16), torch.empty((M, K), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
+           for _ in range(n_rot)]
+
+    def k1_rot():
+        for xr_, qr_, sr_ in rot:
+            L.check(lib.pq_quant_rowwise(xr_.data_ptr(), 0, M, K, K, qr_.data_ptr(), K, sr_.data_ptr(), st()), "pq_quant_rowwise")
+    g_rot = graph_of(k1_rot, 2)
+    g_rot.replay(); torch.cuda.synchronize()
+    t_k1_hot = t_k1
+    t_k1 = med([ev_us(g_rot, 2 * n_rot) for _ in range(15)])
+    del rot, g_rot
+    # the same K1 kernel on a 4x taller activation (16384 rows; 192 MiB in + out per launch, two rotating inputs): the fixed part of
+    # a launch (ramp + tail, ~1.4 us) weighs less
     k1_big = None
     if not tp:
         Mb = 4 * M
-        xb_ = torch.randn(Mb, K, device=dev).to(torch.bfloat16)
-        qb_ = torch.empty((Mb, K), dtype=torch.int8, device=dev); sb_ = torch.empty((Mb,), dtype=torch.float32, device=dev)
-        gb_ = graph_of(lambda: L.check(lib.pq_quant_rowwise(xb_.data_ptr(), 0, Mb, K, K, qb_.data_ptr(), K, sb_.data_ptr(), st()), "pq_quant_rowwise"), 10)
+        bigs = [(torch.randn(Mb, K, device=dev).to(torch.bfloat16), torch.empty((Mb, K), dtype=torch.int8, device=dev), torch.empty((Mb,), dtype=torch.float32, device=dev))
+                for _ in range(3)]
+
+        def k1_big_rot():
+            for xb_, qb_, sb_ in bigs:
+                L.check(lib.pq_quant_rowwise(xb_.data_ptr(), 0, Mb, K, K, qb_.data_ptr(), K, sb_.data_ptr(), st()), "pq_quant_rowwise")
+        gb_ = graph_of(k1_big_rot, 3)
         gb_.replay(); torch.cuda.synchronize()
-        tb = med([ev_us(gb_, 10) for _ in range(15)])
+        tb = med([ev_us(gb_, 9) for _ in range(15)])
         k1_big = {"rows": Mb, "cols": K, "avg_kernel_us": round(tb, 2), "achieved": round((3 * Mb * K + 4 * Mb) / tb / 1e3, 1), "unit": "GB/s",
-                  "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4)}
-        del xb_, qb_, sb_
+                  "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4), "how": "three rotating 16384 x 4096 inputs (576 MiB per round): HBM-fed"}
+        del bigs, gb_
     if tp:
         fence()
-    consistent = (t_gemm + t_k1) <= 1.05 * t_stepc
+    consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)       # cache-hot K1 <= in-step K1 <= HBM-cold K1
     assert consistent or args.no_consistency_check or args.share_gpu, \
-        f"inconsistent timings: GEMM {t_gemm:.2f} us + K1 {t_k1:.2f} us > 1.05 x compute step {t_stepc:.2f} us"
+        f"inconsistent timings: GEMM {t_gemm:.2f} us + K1 {t_k1_hot:.2f} (cache-resident) .. {t_k1:.2f} us (HBM) vs compute step {t_stepc:.2f} us"
 
     ops_job = 2.0 * M * N * K * (1 if tp else world)       # whole job per step
     value = ops_job * K_steps / dt / 1e12
@@ -663,10 +731,13 @@ def main():
                      "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
                      "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_min": round(min(tk3), 2),
                      "how": f"median of {len(tk3)} hipGraph replays of {PG} back-to-back launches, HIP events on the launch stream (includes the ~1 us kernel boundary; rocprofv3 kernel-trace: profiles/)",
-                     "in_step_us": round(t_stepc - t_k1, 2), "traffic": None, "algorithmic_bytes": gemm_bytes},
+                     "traffic": None, "algorithmic_bytes": gemm_bytes},
         "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1),
                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4),
-                       "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes, "same_kernel_4x_rows": k1_big},
+                       "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes,
+                       "how": f"gap-free hipGraph replays rotating over {n_rot} distinct input/output pairs ({n_rot * 3 * M * K // 2**20} MiB > L2 + Infinity Cache): every launch is HBM-fed",
+                       "in_step_us": round(t_stepc - t_gemm, 2), "cache_resident_replay_us": round(t_k1_hot, 2),
+                       "same_kernel_4x_rows": k1_big},
         "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
     }
     tj = os.path.join(ROOT, "profiles", "traffic.json")
@@ -724,6 +795,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         out["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / float(tt.item()) / 1e12, 2), "unit": "TOPS", "scaling": "weak",
                      "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
+    if world == 1 and not args.no_gpu_context:
+        x_, _xq, _xs, y_, wq_, ws_, _w = _keep
+        k1(); k3(); torch.cuda.synchronize()
+        out["gpu_context"] = gpu_context(x_, wq_, ws_, y_, med)
+        t_pipe = out["gpu_context"].get("torch_rocm_int8_pipeline_us")
+        if t_pipe:
+            out["gpu_context"]["library_step_us"] = round(t_stepc, 2)
+            out["gpu_context"]["speedup_vs_torch_rocm_int8_pipeline"] = round(t_pipe / t_stepc, 2)
+            out["gpu_context"]["speedup_vs_torch_bf16_linear"] = round(out["gpu_context"]["torch_bf16_linear_us"] / t_stepc, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(M, N, K)
     elif rank == 0:

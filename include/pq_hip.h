@@ -129,6 +129,11 @@ int32_t pq_qlinear_dyn(const void* x, int32_t dtype, int64_t ld_x, const int8_t*
 int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits, int64_t n,
                                   unsigned long long* mismatches, void* stream);
 
+/* Self-test hook: enumerates on the GPU the WHOLE domain of the one-step division-free encode that 16-bit inputs take (dtype 0 = bf16,
+ * 1 = fp16): every amax bit pattern whose scale takes the fast path x every magnitude pattern <= amax x both signs.  counts[0] += pairs
+ * checked, counts[1] += pairs whose code differs from clamp(rne(x / s)).  counts[2] must be zeroed by the caller.  QSPEC Q4. */
+int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void* stream);
+
 /* Name of the GEMM kernel variant the dispatcher would pick for this problem (static string). */
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 

@@ -25,11 +25,13 @@ template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
+void set_k1_lds(int);
 void set_ring_lc(bool);
 void set_sp128_lc(bool);
 void set_silu_tpr(int);
 void set_rms_wave_max(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
+void launch_half_encode_check(int, unsigned long long*, hipStream_t);
 }  // namespace pq
 
 namespace {
@@ -212,6 +214,7 @@ int32_t pq_set_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
@@ -435,6 +438,12 @@ int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits
     if (!x_bits || !s_bits || !mismatches || n < 0) return fail(PQ_ERR_BAD_ARG, "pq_selftest_fast_quotient: bad arguments");
     pq::launch_fast_quotient_check(x_bits, s_bits, n, mismatches, static_cast<hipStream_t>(stream));
     return check_launch("pq_selftest_fast_quotient");
+}
+
+int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void* stream) {
+    if (!counts || (dtype != PQ_BF16 && dtype != PQ_FP16)) return fail(PQ_ERR_BAD_ARG, "pq_selftest_half_encode: dtype must be bf16 or fp16, counts non-null");
+    pq::launch_half_encode_check(dtype, counts, static_cast<hipStream_t>(stream));
+    return check_launch("pq_selftest_half_encode");
 }
 
 #ifdef PQ_ABLATION_BUILD

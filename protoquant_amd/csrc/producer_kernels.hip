@@ -181,8 +181,10 @@ __device__ __forceinline__ void fast_encode_vec(const v4u& hv, float s, float r,
         v2f q = x * vr;
         v2f e = pk_fma(-q, vs, x);
         q = pk_fma(e, vr, q);
-        e = pk_fma(-q, vs, x);
-        q = pk_fma(e, vr, q);
+        if constexpr (kQuotientSteps<DT> == 2) {          // 16-bit h: one step is exact for the code (quant_device.h)
+            e = pk_fma(-q, vs, x);
+            q = pk_fma(e, vr, q);
+        }
         const v2f m = q + splat(kMagic);
         const float mx = m.x, my = m.y;       // copies first (same hipcc quirk)
         mb[2 * j] = __builtin_bit_cast(uint32_t, mx);
@@ -200,7 +202,7 @@ template <int DT, int VPT, int TPR>
 __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t ab, int t, int nvec, bool active, int64_t row,
                                                   int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
     constexpr int EPV = 16 / Elem<DT>::kBytes;
-    ab = wave_max_u32(ab);
+    ab = wave_max_u32(amax_acc_finish<DT>(ab));       // `ab` arrives as vec_amax_bits' accumulator
     constexpr int NW = (TPR > 256 ? TPR : 256) / kWave;      // waves of the block (a row group wider than a wave is the whole block)
     __shared__ uint32_t part[NW];
     if constexpr (TPR > kWave) {

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
         uint32_t ab = 0;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) ab = vec_amax_bits<DT>(v[rr][i], ab);
-        ab = wave_max_u32(ab);
+        ab = wave_max_u32(amax_acc_finish<DT>(ab));
         if constexpr (TPR > kWave) {
             if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = ab;
             __syncthreads();
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
                 float f[EPV];
                 Unpack<DT, EPV>::run(v[rr][i], f);
                 uint32_t pk[EPV / 4];
-                fast_encode<EPV>(f, s, r, pk);
+                fast_encode<EPV, kQuotientSteps<DT>>(f, s, r, pk);
                 if (idx < nvec) store_vec(idx, pk);
             }
         } else {                                  // uniform per row group: true division (NaN/Inf data, extreme scales)
@@ -133,6 +133,34 @@ __global__ void fast_quotient_check(const uint32_t* __restrict__ xbits, const ui
 }
 void launch_fast_quotient_check(const uint32_t* xb, const uint32_t* sb, int64_t n, unsigned long long* out, hipStream_t st) {
     fast_quotient_check<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(xb, sb, n, out);
+}
+
+// dev/test kernel: the WHOLE domain of the one-step encode of a 16-bit format (quant_device.h: quotient_fast1).  Block b owns the amax
+// bit pattern b + 1; its threads walk every magnitude pattern <= amax with both signs.  out[0] += pairs on the fast path,
+// out[1] += pairs whose code differs from code_of(x, s) (true division + rintf).
+template <int DT>
+__global__ __launch_bounds__(256) void half_encode_check(unsigned long long* __restrict__ out) {
+    const uint32_t a = blockIdx.x + 1u;
+    const float s = scale_of(Elem<DT>::to_f32((uint16_t)a));
+    if (!scale_fast_ok(s)) return;
+    const float r = 1.0f / s;
+    unsigned long long n = 0, bad = 0;
+    for (uint32_t xb = threadIdx.x; xb <= a; xb += 256u) {
+#pragma unroll
+        for (uint32_t sign = 0; sign < 2; ++sign) {
+            const float x = Elem<DT>::to_f32((uint16_t)(xb | (sign << 15)));
+            const uint32_t fast = __builtin_bit_cast(uint32_t, quotient_fast1(x, s, r) + kMagic) & 0xFFu;
+            const uint32_t want = (uint32_t)code_of(x, s) & 0xFFu;
+            ++n;
+            bad += fast != want ? 1u : 0u;
+        }
+    }
+    atomicAdd(&out[0], n);
+    if (bad) atomicAdd(&out[1], bad);
+}
+void launch_half_encode_check(int dtype, unsigned long long* out, hipStream_t st) {
+    if (dtype == PQ_BF16) half_encode_check<PQ_BF16><<<dim3(0x7F7Fu), dim3(256), 0, st>>>(out);        // every finite positive pattern
+    else half_encode_check<PQ_FP16><<<dim3(0x7BFFu), dim3(256), 0, st>>>(out);
 }
 
 // K1 generic path: any cols / leading dimension / alignment.  One block per row, two passes over the
@@ -319,6 +347,8 @@ static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<u
 
 int g_k1_rpw = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_K1_RPW"))
 void set_k1_rpw(int v) { g_k1_rpw = v; }
+int g_k1_lds = 0;     // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU (pq_set_option("PQ_K1_LDS"))
+void set_k1_lds(int v) { g_k1_lds = v < 0 ? 0 : (v > 65536 ? 65536 : v); }
 
 template <int DT, int TPR>
 static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, int64_t ldx_bytes, int8_t* q,
@@ -335,20 +365,20 @@ static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, i
         if (two && vpt <= 8) {
             const dim3 grid2((unsigned)((rows + 2 * RPB - 1) / (2 * RPB))), block(256);
             switch (vpt) {
-                case 1: quant_rowwise_vec<DT, 1, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                case 2: quant_rowwise_vec<DT, 2, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                case 4: quant_rowwise_vec<DT, 4, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                default: quant_rowwise_vec<DT, 8, TPR, 2><<<grid2, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 1: quant_rowwise_vec<DT, 1, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 2: quant_rowwise_vec<DT, 2, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 4: quant_rowwise_vec<DT, 4, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                default: quant_rowwise_vec<DT, 8, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
             }
         }
     }
     const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
     switch (vpt) {
-        case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 4: quant_rowwise_vec<DT, 4, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 8: quant_rowwise_vec<DT, 8, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        default: quant_rowwise_vec<DT, 16, TPR><<<grid, block, 0, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 4: quant_rowwise_vec<DT, 4, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 8: quant_rowwise_vec<DT, 8, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        default: quant_rowwise_vec<DT, 16, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
     }
 }
 

@@ -384,6 +384,19 @@ def test_fast_quotient_bruteforce(pq):
     assert out.tolist() == [0, 0], f"fast quotient mismatches (codes, quotients): {out.tolist()}"
 
 
+@pytest.mark.parametrize("dtype_code,name,min_pairs", [(0, "bf16", 5.0e8), (1, "fp16", 1.0e9)])
+def test_half_encode_whole_domain(pq, dtype_code, name, min_pairs):
+    """16-bit rows take ONE residual correction (quant_device.h: quotient_fast1).  The GPU enumerates that path's whole domain with its
+    own fma — every amax pattern whose scale is on the fast path x every magnitude <= amax x both signs — against true division + rintf
+    (the host repeats the enumeration in C: tests/test_half_quotient_identity.py)."""
+    from protoquant_amd import _lib
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().pq_selftest_half_encode(dtype_code, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    pairs, bad = out.tolist()
+    assert pairs > min_pairs and bad == 0, f"{name}: {pairs} pairs, {bad} mismatches"
+
+
 def test_column_sharded_world1_matches_unsharded(pq):
     """ColumnShardedQLinear over RCCL (backend nccl) with a 1-rank group == plain qlinear, bit for bit."""
     import torch.distributed as dist
