@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3a
-python3 tools/k1_feed_probe.py - PQ_K1_RPW=2 PQ_K1_LDS=65536 PQ_K1_LDS=49152 PQ_K1_LDS=40000 PQ_K1_RPW=2,PQ_K1_LDS=65536 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3a/k1_feed.txt
-python3 tools/k1_feed_probe.py --rows 16384 - PQ_K1_RPW=2 PQ_K1_LDS=65536 PQ_K1_LDS=40000 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r3a/k1_feed.txt
+mkdir -p gpurun_out/r3b
+timeout 300 tools/ubench/k1_feed 2>&1 | tee gpurun_out/r3b/k1_feed_ubench.txt
