@@ -95,7 +95,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // the same barriers.  The 8-wave form of this tile runs ~1900 cycles per K-tile against 1024 of MFMA because all 8 waves stall in
 // their DMA issues at the same point of the tile; here a SIMD's consumer never issues a DMA.  It also reads 96 instead of 160 KiB
 // of LDS fragments per K-tile (the wave tile is twice as tall).
-template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false>   // ABL: compile-time ablation (0 = product)
+// P3 (TM = TN = 256 only): SPLIT rings — the weight (P) half-tiles in a ring of THREE 32-KiB slots, the activation (Q) half-tiles
+// in a ring of two; 160 KiB, all of the LDS.  The weights of a model layer are read once per pass, from HBM: measured, a launch
+// whose weights are not in the Infinity Cache runs its K-loop in 92 K instead of 76 K cycles with the 2-deep ring (every K-tile
+// waits ~500 cycles for its first-touch pieces: one K-tile of lead is ~1 000 cycles, HBM under load answers in ~1 700), 5-9 % of
+// the launch.  Here a weight piece is issued TWO K-tiles before it is needed.  The activations were written by the previous
+// kernel and come from the Infinity Cache: one K-tile of lead is enough for them.  No LDS of their own is left for the scale vectors:
+// they are DMA'd, two K-tiles before the epilogue, into the P slot that no later tile needs.
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -126,10 +133,14 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr int PHB = (TN / 2) * FBK, QHB = (TM / 2) * FBK;   // bytes of a P / Q half-tile
     constexpr int BUFB = 2 * PHB + 2 * QHB;                      // 64, 48 or 32 KiB
     constexpr int NBUF = (TM == 128 && TN == 256) ? 3 : 2;
+    constexpr int PB = 2 * PHB, QB = 2 * QHB;                    // bytes of one K-tile's P / Q side
+    constexpr int NPB = P3 ? 3 : NBUF, NQB = P3 ? 2 : NBUF;      // ring depths of the two sides (equal, and interleaved slot by slot, unless P3)
+    constexpr int QBASE = P3 ? NPB * PB : 0;                     // P3: [P slot 0..2][Q slot 0..1]; otherwise [slot: P h0, P h1, Q h0, Q h1]...
     constexpr int SCALE_OFF = NBUF * BUFB;                                                 // ring (and, in a free slot, the epilogue staging) below, scales above
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SCALE_OFF + 2048];                // + 1 KiB row scales + 1 KiB column scales
+    __shared__ __attribute__((aligned(16))) uint8_t smem[P3 ? NPB * PB + NQB * QB : SCALE_OFF + 2048];   // (not P3) + 1 KiB row scales + 1 KiB column scales
 
     static_assert(!LC || (TM == 128 && TN == 256), "loader / consumer split: 128 x 256 tile only");
+    static_assert(!P3 || (TM == 256 && TN == 256 && !LC), "split rings: 256 x 256 tile only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = LC && wave >= 4;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     for (int ks = 0; ks < NKS; ++ks) {
         const int c = ks * (8 / NKS) + fchunk;
         lP[ks] = (uint32_t)((wp * PWH + frow) * 128 + ((c ^ fkey) * 16));
-        lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16)) + 2 * PHB;
+        lQ[ks] = (uint32_t)((wq * QW + frow) * 128 + ((c ^ fkey) * 16));
     }
 
     using acc_t = v4i;
@@ -232,40 +243,58 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     // ---- issue items.  Everything below is hand-interleaved: ONE item in the shadow of each MFMA.
     // DMA piece g of a K-tile, in need order P0 (PPW pieces) | Q0 (QPW pieces) | Q1 (QPW pieces) | P1 (PPW pieces)
     constexpr int NDMA = 2 * PPW + 2 * QPW;
-    auto dma_item = [&](int buf, auto gc) {
+    // LDS byte offset of slot ps of the P ring / slot qs of the Q ring
+    auto p_off = [&](int ps) { return P3 ? ps * PB : ps * BUFB; };
+    auto q_off = [&](int qs) { return P3 ? QBASE + qs * QB : qs * BUFB + PB; };
+    auto dma_piece = [&](auto isq_c, auto h_c, auto jj_c, int off) {   // one 1-KiB piece of half h of the side whose slot starts at `off`
+        constexpr bool isQ = decltype(isq_c)::value;
+        constexpr int h = decltype(h_c)::value, jj = decltype(jj_c)::value;
+        if (!no_dma) {
+            if constexpr (isQ) glds16_sbase(gQ, offQ[h][jj], smem_base + off + h * QHB + (w * QPW + jj) * 1024);
+            else glds16_sbase(gP, offP[h][jj], smem_base + off + h * PHB + piece_off + jj * 1024);
+        }
+    };
+    auto dma_item = [&](int buf, auto gc) {       // both sides of one K-tile into slot `buf` of each ring, need order P0 | Q0 | Q1 | P1
         constexpr int g = decltype(gc)::value;
         if constexpr (g < NDMA) {
             constexpr bool isQ = (g >= PPW && g < PPW + 2 * QPW);
             constexpr int h = isQ ? (g - PPW) / QPW : (g >= PPW ? 1 : 0);
             constexpr int jj = isQ ? (g - PPW) % QPW : (g < PPW ? g : g - PPW - 2 * QPW);
-            if (!no_dma) {
-                if constexpr (isQ) {
-                    const uint32_t la = smem_base + buf * BUFB + 2 * PHB + h * QHB + (w * QPW + jj) * 1024;
-                    glds16_sbase(gQ, offQ[h][jj], la);
-                } else {
-                    const uint32_t la = smem_base + buf * BUFB + h * PHB + piece_off + jj * 1024;
-                    glds16_sbase(gP, offP[h][jj], la);
-                }
-            }
+            dma_piece(std::integral_constant<bool, isQ>{}, std::integral_constant<int, h>{}, std::integral_constant<int, jj>{}, isQ ? q_off(buf) : p_off(buf));
             if constexpr (g == NDMA - 1) { gP += FBK; gQ += FBK; }
+        }
+    };
+    // P3 steady state: the Q side of tile kt+2 FIRST (it is needed one K-tile earlier: the mid-tile wait may leave the P pieces behind
+    // it in flight), then — if tile kt+3 exists — its P side.  gQ and gP walk independently (gQ is one tile behind gP).
+    auto dma_item3 = [&](int ps, int qs, auto gc, auto with_p) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < 2 * QPW) {
+            dma_piece(std::true_type{}, std::integral_constant<int, g / QPW>{}, std::integral_constant<int, g % QPW>{}, q_off(qs));
+            if constexpr (g == 2 * QPW - 1) gQ += FBK;
+        } else if constexpr (g < NDMA && decltype(with_p)::value) {
+            constexpr int gp = g - 2 * QPW;
+            dma_piece(std::false_type{}, std::integral_constant<int, gp / PPW>{}, std::integral_constant<int, gp % PPW>{}, p_off(ps));
+            if constexpr (g == NDMA - 1) gP += FBK;
         }
     };
     auto stage_tile = [&](int buf) {   // whole tile at once (prologue only)
         static_for<NDMA>([&](auto gc) { dma_item(buf, gc); });
     };
+    auto stage_q = [&](int qs) { static_for<2 * QPW>([&](auto gc) { dma_item3(0, qs, gc, std::false_type{}); }); };                               // P3 prologue
+    auto stage_p = [&](int ps) { static_for<2 * PPW>([&](auto gc) { dma_item3(ps, 0, std::integral_constant<int, 2 * QPW + decltype(gc)::value>{}, std::true_type{}); }); };
     // fragment item it: P: i = it % NPI, ks = it / NPI (NPR items); Q: j = it % NQJ, ks = it / NQJ (NQR items)
-    auto readP_item = [&](int bufoff, int h, v4i (&f)[NPI][NKS], auto ic) {
+    auto readP_item = [&](int poff, int h, v4i (&f)[NPI][NKS], auto ic) {        // poff = p_off(slot)
         constexpr int it = decltype(ic)::value, i = it % NPI, ks = it / NPI;
-        if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lP[ks] + h * PHB + i * SHAPE * 128);
+        if (!no_lds) f[i][ks] = *reinterpret_cast<const v4i*>(smem + poff + lP[ks] + h * PHB + i * SHAPE * 128);
     };
-    auto readQ_item = [&](int bufoff, int h, v4i (&f)[NQJ][NKS], auto ic) {
+    auto readQ_item = [&](int qoff, int h, v4i (&f)[NQJ][NKS], auto ic) {        // qoff = q_off(slot)
         constexpr int it = decltype(ic)::value, j = it % NQJ, ks = it / NQJ;
-        if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + bufoff + lQ[ks] + h * QHB + j * SHAPE * 128);
+        if (!no_lds) f[j][ks] = *reinterpret_cast<const v4i*>(smem + qoff + lQ[ks] + h * QHB + j * SHAPE * 128);
     };
     constexpr int NPR = NPI * NKS;               // P fragment reads per half: 8 or 4
-    auto readP = [&](int bufoff, int h, v4i (&f)[NPI][NKS]) { static_for<NPR>([&](auto ic) { readP_item(bufoff, h, f, ic); }); };
+    auto readP = [&](int poff, int h, v4i (&f)[NPI][NKS]) { static_for<NPR>([&](auto ic) { readP_item(poff, h, f, ic); }); };
     constexpr int NQR = NQJ * NKS;               // Q fragment reads per half: 4 or 2
-    auto readQ = [&](int bufoff, int h, v4i (&f)[NQJ][NKS]) { static_for<NQR>([&](auto ic) { readQ_item(bufoff, h, f, ic); }); };
+    auto readQ = [&](int qoff, int h, v4i (&f)[NQJ][NKS]) { static_for<NQR>([&](auto ic) { readQ_item(qoff, h, f, ic); }); };
 
     constexpr int NM = NKS * NPI * NQJ;          // MFMAs per quadrant: 16, 8 or 4
     constexpr int PPS = NPR / (NM / 2);          // P reads per slot (half a quadrant's slots): 1 or 2
@@ -290,6 +319,27 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     const int NT = Ks / FBK;
 
+    // this wave's WM(m) x WN(n) block of the output tile (epilogue coordinates; D[row <-> n][col <-> m]: a lane holds 4 consecutive n)
+    const int dcol = lane & 15;                                             // m inside a Q tile
+    const int drow4 = (lane >> 4) * 4;                                      // first of 4 consecutive n
+    constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
+    constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
+    const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;
+    // the staged epilogue reads the scale vectors 16 bytes at a time (LDS image filled by DMA, or — P3 — registers filled in the last K-tile)
+    const bool scales_ok = (OUT == OUT_I32) ||
+        ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
+    // Where the tile's 256 row scales and 256 column scales sit in LDS for the epilogue (1 KiB each, by DMA).  P3 has no LDS of its
+    // own left for them: they go to the P slot that tile NT-3 vacates — no later tile's DMA targets it — issued in that tile (or, for
+    // NT < 3, in the prologue: that slot is never used then), i.e. two K-tiles before the epilogue needs them.
+    const int scale_off = P3 ? p_off((Ks / FBK) % 3) : SCALE_OFF;
+    auto scale_dma = [&]() {       // waves 0 and 1 (of the issuing role): 4 floats per lane, clamped at the matrix edge
+        const int base = w == 0 ? m0 : n0, lim = w == 0 ? M : N;
+        int e0 = base + lane * 4;
+        e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
+        const float* src = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
+        glds16_vaddr(src, smem_base + scale_off + w * 1024);
+    };
+
     // One K-tile, branch-free inside (flags are compile-time).  Quadrant order (P0,Q0) (P0,Q1) (P1,Q0)
     // (P1,Q1): every register set returns to the same role each tile.  Entry: fPa = P0[kt], fQa = Q0[kt].
     //   q0: MFMA acc[0][0] (fPa, fQa)   | slots: read Q1[kt] -> fQb
@@ -303,37 +353,57 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     // first MFMAs' C operand and spill): the prologue waited for P0 and Q0 alone; Q1 and P1 are waited for (and published
     // with a barrier) right before the quadrants whose shadows read them.  VMA = DMA pieces issued after tile 0's in the
     // prologue, a compile-time function of the flavour.
-    auto tile = [&](int kt, int slot, auto has_next, auto has_next2, auto has_dma) {
-        const int bufoff = slot * BUFB;
-        const int nextoff = (slot + 1 == NBUF ? 0 : slot + 1) * BUFB;
+    // P3: `slot` is the P ring's slot (kt % 3), `qslot` the Q ring's (kt % 2); has_dma = tile kt+3 exists (its P side is issued here; the Q
+    // side of tile kt+2 whenever that tile exists).  Otherwise qslot == slot.
+    auto tile = [&](int kt, int slot, int qslot, auto has_next, auto has_next2, auto has_dma) {
+        const int poff = p_off(slot), qoff = q_off(qslot);
+        const int poffn = p_off(slot + 1 == NPB ? 0 : slot + 1), qoffn = q_off(qslot + 1 == NQB ? 0 : qslot + 1);
         constexpr bool next = decltype(has_next)::value, next2 = decltype(has_next2)::value, dma = decltype(has_dma)::value;
-        constexpr int VMA = !next ? 0 : ((NBUF == 3 && next2) ? 2 * NDMA : NDMA);
+        // VMA: DMA pieces younger than tile 0's when tile 0 waits for its Q1 / P1.  P3: tile 1 from the prologue; the P side of tile 2 is
+        // issued in tile 0's first quadrant (below) — in the prologue it cost every wave four more issue stalls before the first MFMA
+        constexpr int VMA = !next ? 0 : (P3 ? NDMA : ((NBUF == 3 && next2) ? 2 * NDMA : NDMA));
+        constexpr int VMA1 = VMA + ((P3 && next2) ? 2 * PPW : 0);
         // (LC: the loaders do the vmcnt waits; a consumer only retires its own LDS reads before each barrier)
         if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(LC ? 63 : VMA + PPW, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }   // Q1 of tile 0 visible
         mma(acc[0][0], fPa, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (x < NQR) readQ_item(bufoff, 1, fQb, xc);
+            if constexpr (x < NQR) readQ_item(qoff, 1, fQb, xc);
+            if constexpr (P3 && next2 && x >= NQR && x < NQR + 2 * PPW) {
+                if (kt == 0) dma_item3(2, 0, std::integral_constant<int, 2 * QPW + (x - NQR)>{}, std::true_type{});       // P side of tile 2 -> P slot 2
+            }
         });
-        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(LC ? 63 : VMA, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }         // P1 of tile 0 visible
+        if (!no_vmwait && kt == 0) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(LC ? 63 : VMA1, 0)); if constexpr (!no_barrier) __builtin_amdgcn_s_barrier(); }        // P1 of tile 0 visible
         mma(acc[0][1], fPa, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(bufoff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+            if constexpr (x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(poff, 1, fPb, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
         });
         if constexpr (next) {
-            // tile kt+1 must have landed; with a 3-deep ring tile kt+2 (NDMA pieces per wave) may stay in flight
+            // tile kt+1 must have landed; with a 3-deep ring tile kt+2 (NDMA pieces per wave) may stay in flight; with split rings
+            // the P side of tile kt+2 (2 * PPW pieces, issued behind the Q side of tile kt+1) may
             if constexpr (no_vmwait || LC) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   // lgkmcnt(0) only
+            else if constexpr (P3 && next2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * PPW, 0));
             else if constexpr (NBUF == 3 && next2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(NDMA, 0));
             else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));   // vmcnt(0) lgkmcnt(0): builtin form, so hipcc's scoreboard knows
             if constexpr (!no_barrier) __builtin_amdgcn_s_barrier();
         }
         mma(acc[1][0], fPb, fQa, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(nextoff, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
-            if constexpr (dma && !LC && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(slot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
+            if constexpr (next && x < NM / 2) static_for<PPS>([&](auto pc) { readP_item(poffn, 0, fPa, std::integral_constant<int, x * PPS + decltype(pc)::value>{}); });
+            if constexpr (P3) {
+                if constexpr (next2 && x >= NM / 2)
+                    static_for<DPS>([&](auto pc) { dma_item3(slot, qslot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}, has_dma); });
+                // tile NT-3 (the one flavour with a tile kt+2 but no tile kt+3): the scale vectors follow the Q pieces into the P slot
+                // this tile has just vacated; the vmcnt(0) of tile NT-2's mid-tile wait covers them, its barrier publishes them
+                if constexpr (next2 && !dma && OUT != OUT_I32 && x == NM / 2 + 2 * QPW) {
+                    if (scales_ok && w < 2) scale_dma();
+                }
+            } else {
+                if constexpr (dma && !LC && x >= NM / 2) static_for<DPS>([&](auto pc) { dma_item(slot, std::integral_constant<int, (x - NM / 2) * DPS + decltype(pc)::value>{}); });
+            }
         });
         mma(acc[1][1], fPb, fQb, [&](auto xc) {
             constexpr int x = decltype(xc)::value;
-            if constexpr (next && x < NQR) readQ_item(nextoff, 0, fQa, xc);
+            if constexpr (next && x < NQR) readQ_item(qoffn, 0, fQa, xc);
         });
     };
     constexpr std::true_type yes{};
@@ -342,22 +412,21 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     // ---- prologue: the tile's 256 row scales and 256 column scales go to LDS by DMA (waves 0 and 1, 4 floats per
     // lane, clamped at the matrix edge) so the epilogue never waits on a global load; then tiles 0 and 1.
     // (only when both scale vectors are 16-byte aligned and at least 4 long; otherwise the direct epilogue is used)
-    const bool scales_in_lds = (OUT == OUT_I32) ||
-        ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
+    const bool scales_in_lds = scales_ok;
     if constexpr (OUT != OUT_I32) {
-        if (scales_in_lds && w < 2 && (!LC || loader)) {
-            const int base = w == 0 ? m0 : n0, lim = w == 0 ? M : N;
-            int e0 = base + lane * 4;
-            e0 = e0 + 3 < lim ? e0 : (lim >= 4 ? lim - 4 : 0);     // edge tiles: any valid address (values unused there)
-            const float* src = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
-            glds16_vaddr(src, smem_base + SCALE_OFF + w * 1024);     // (one more piece ahead of this wave's tile pieces: waited for with them)
-        }
+        if (scales_in_lds && w < 2 && (!LC || loader) && (!P3 || Ks / FBK < 3))
+            scale_dma();                                             // (one more piece ahead of this wave's tile pieces: waited for with them)
     }
-    const int vm_after = ((NT < NBUF ? NT : NBUF) - 1) * NDMA;      // DMA pieces (per issuing wave) behind tile 0's
+    // DMA pieces (per issuing wave) behind tile 0's
+    const int vm_after = P3 ? (NT > 1 ? NDMA : 0) : ((NT < NBUF ? NT : NBUF) - 1) * NDMA;
     if (!LC || loader) {
         stage_tile(0);
-        if (NT > 1) stage_tile(1);
-        if (NBUF == 3 && NT > 2) stage_tile(2);
+        if constexpr (P3) {            // tile 1, Q side first (the P side of tile 2 follows in tile 0's first quadrant): gQ and gP end at tile 2
+            if (NT > 1) { stage_q(1); stage_p(1); }
+        } else {
+            if (NT > 1) stage_tile(1);
+            if (NBUF == 3 && NT > 2) stage_tile(2);
+        }
         // wait for the first half of tile 0 only (P0, Q0 — pieces are issued in need order P0 | Q0 | Q1 | P1): the rest of
         // tile 0 and the other staged tiles stay in flight
         if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
@@ -385,17 +454,18 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         }
     }
     stamp(1);
-    readP(0, 0, fPa);
-    readQ(0, 0, fQa);
+    readP(p_off(0), 0, fPa);
+    readQ(q_off(0), 0, fQa);
 
-    int kt = 0, slot = 0;
-    auto adv = [&]() { ++kt; slot = (slot + 1 == NBUF) ? 0 : slot + 1; };
-    while (kt + NBUF < NT) { tile(kt, slot, yes, yes, yes); adv(); }
-    if constexpr (NBUF == 3) {
-        if (kt + 2 < NT) { tile(kt, slot, yes, yes, no); adv(); }
+    int kt = 0, slot = 0, qslot = 0;
+    constexpr int DEPTH = P3 ? 3 : NBUF;      // tiles ahead of the current one whose (P-side) DMA is issued in it
+    auto adv = [&]() { ++kt; slot = (slot + 1 == NPB) ? 0 : slot + 1; qslot = (qslot + 1 == NQB) ? 0 : qslot + 1; };
+    while (kt + DEPTH < NT) { tile(kt, slot, qslot, yes, yes, yes); adv(); }
+    if constexpr (DEPTH == 3) {
+        if (kt + 2 < NT) { tile(kt, slot, qslot, yes, yes, no); adv(); }
     }
-    if (kt + 1 < NT) { tile(kt, slot, yes, no, no); adv(); }
-    tile(kt, slot, no, no, no);
+    if (kt + 1 < NT) { tile(kt, slot, qslot, yes, no, no); adv(); }
+    tile(kt, slot, qslot, no, no, no);
 
     stamp(2);
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
@@ -419,12 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr int OB = (int)sizeof(O);
     O* y = reinterpret_cast<O*>(epi.y) + (int64_t)kslice * M * epi.ldy;   // slab of this K-slice (kslices == 1: the output itself)
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
-    const int dcol = lane & 15;                                             // m inside a Q tile
-    const int drow4 = (lane >> 4) * 4;                                      // first of 4 consecutive n
     constexpr int NG = 1;
-    constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
-    constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
-    const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;                       // this wave's WM(m) x WN(n) block
 
     // staged path: whole block in range, 16-byte aligned rows
     const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
@@ -435,16 +500,19 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
         // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
         constexpr int WREG = BUFB / (LC ? 4 : 8);                           // 8, 6 or 4 KiB (LC: 12 KiB for each of the 4 consumers)
+        // (P3: the P slot and the Q slot of tile NT-2 — read for the last time before a barrier every wave has passed, and no DMA
+        // targets them again — four waves each; the third free slot, tile NT-3's P slot, holds the scales)
         const int last_slot = (NT - 1) % NBUF;
-        const uint32_t sw_off = (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
+        const uint32_t sw_off = P3 ? (uint32_t)((w < 4 ? p_off((NT + 1) % 3) : q_off(NT % 2)) + (w & 3) * WREG)
+                                   : (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
         constexpr int NPT = 2 * NPI, NQT = 2 * NQJ;                         // column / row tiles of the wave block
         constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;      // staged rows of at most 256 bytes
         constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
         constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
         static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= WREG, "epilogue staging region");
         auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt / NPI][qt / NQJ][pt % NPI][qt % NQJ]; };
-        auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + SCALE_OFF)[wq * WM + qt * 16 + dcol]; };
-        auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + SCALE_OFF + 1024 + (wp * WN + pt * 16 + drow4) * 4); };
+        auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + qt * 16 + dcol]; };
+        auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + scale_off + 1024 + (wp * WN + pt * 16 + drow4) * 4); };
         uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0);
         const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0)) : nullptr;
         PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane);
@@ -513,6 +581,8 @@ int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(
 
 bool g_sp128_lc = true;     // loader / consumer split of the 128 x 256 tile (pq_set_option("PQ_SP128_LC", "0") restores the 8-wave form)
 void set_sp128_lc(bool v) { g_sp128_lc = v; }
+bool g_sp256_p3 = true;     // split rings of the 256 x 256 tile: weights 3 slots deep (pq_set_option("PQ_SP256_P3", "0") restores the 2-deep ring)
+void set_sp256_p3(bool v) { g_sp256_p3 = v; }
 
 template <int OUT, int TM, int TN>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
@@ -527,6 +597,14 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     }
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && TM == 256 && TN == 256) {
+        if (g_sp256_p3) {
+            switch (gemm_debug_flags()) {
+#define PQ_ABL3(n) case n: gemm_s8_sp256<OUT, n, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
+                PQ_ABL3(1) PQ_ABL3(2) PQ_ABL3(3) PQ_ABL3(4) PQ_ABL3(8) PQ_ABL3(1024)
+#undef PQ_ABL3
+                default: break;
+            }
+        }
         switch (gemm_debug_flags()) {
 #define PQ_ABL(n) case n: gemm_s8_sp256<OUT, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
             PQ_ABL(1) PQ_ABL(2) PQ_ABL(3) PQ_ABL(4) PQ_ABL(8) PQ_ABL(9) PQ_ABL(10) PQ_ABL(11) PQ_ABL(12) PQ_ABL(13) PQ_ABL(14) PQ_ABL(15) PQ_ABL(16) PQ_ABL(40) PQ_ABL(72) PQ_ABL(104) PQ_ABL(1024)
@@ -535,6 +613,12 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         }
     }
 #endif
+    if constexpr (TM == 256 && TN == 256) {
+        if (g_sp256_p3) {
+            gemm_s8_sp256<OUT, 0, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+            return;
+        }
+    }
     gemm_s8_sp256<OUT, 0, TM, TN><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
 }
 

@@ -28,6 +28,7 @@ void set_k1_rpw(int);
 void set_k1_lds(int);
 void set_ring_lc(bool);
 void set_sp128_lc(bool);
+void set_sp256_p3(bool);
 void set_silu_tpr(int);
 void set_rms_wave_max(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
@@ -213,6 +214,7 @@ int32_t pq_set_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_SP256_P3")) pq::set_sp256_p3(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--per-graph", type=int, default=20)
     ap.add_argument("--bias", action="store_true")
     ap.add_argument("--eager", action="store_true", help="eager back-to-back launches instead of graph replays")
+    ap.add_argument("--rotate-weights", type=int, default=1, help="cycle through this many distinct weight matrices (enough of them: every launch reads its weights from HBM, as inside a model)")
     a = ap.parse_args()
     libs = []
     for spec in a.libs:            # name=path[@OPT=VAL,...]: options go through pq_set_option (load a COPY of the .so for a second setting)
@@ -54,6 +55,7 @@ def main():
         torch.manual_seed(1)
         xq = (torch.randn(M, K, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
         wq = (torch.randn(N, K, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
+        wrot = [wq] + [(torch.randn(N, K, device=dev) * 28).round().clamp(-127, 127).to(torch.int8) for _ in range(a.rotate_weights - 1)]
         xs = torch.rand(M, device=dev) * 1e-2 + 1e-3
         ws = torch.rand(N, device=dev) * 1e-2 + 1e-3
         bias = (torch.randn(N, device=dev) * 0.1).to(dt[0]) if a.bias else None
@@ -64,14 +66,18 @@ def main():
             wb = L.pq_qlinear_workspace_bytes(M, N, K)
             wsp = torch.empty(max(wb, 16), dtype=torch.uint8, device=dev)
 
-            def f(L=L, y=y, wsp=wsp, wb=wb):
+            cnt = [0]
+
+            def f(L=L, y=y, wsp=wsp, wb=wb, cnt=cnt):
+                wq = wrot[cnt[0] % len(wrot)]; cnt[0] += 1
                 rc = L.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(),
                                      bias.data_ptr() if bias is not None else None, y.data_ptr(), N, dt[1], M, N, K,
                                      wsp.data_ptr() if wb else None, wb, torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, L.pq_last_error()
             f()
             torch.cuda.synchronize()
-            outs.append(y)
+            cnt[0] = 0
+            outs.append(y.clone())
             fns.append(f)
             if not a.eager:
                 s2 = torch.cuda.Stream(); s2.wait_stream(torch.cuda.current_stream())

@@ -9,6 +9,9 @@ import protoquant_amd as pq
 from protoquant_amd import _lib as _pqlib  # noqa: E402
 from tools.quick_bench import timeit
 M = N = K = 4096
+if os.environ.get("PQ_ABL_SHAPE"):          # e.g. PQ_ABL_SHAPE=4096x28672x4096 (multi-round grids: stamps are per hardware block id)
+    M, N, K = (int(v) for v in os.environ["PQ_ABL_SHAPE"].split("x"))
+NT = ((M + 255) // 256) * ((N + 255) // 256)
 torch.manual_seed(0)
 if os.environ.get("PQ_ABL_UNIFORM"):
     xq = torch.randint(-127, 128, (M, K), dtype=torch.int8, device="cuda"); wq = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda")
@@ -17,11 +20,13 @@ else:   # gaussian codes, what per-token quantisation of N(0,1) data produces
 xs = torch.rand(M, device="cuda") * 0.01; ws = torch.rand(N, device="cuda") * 0.01
 out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
 _pqlib.set_option("PQ_FORCE_VARIANT", "sp256_16")
+for kv in filter(None, os.environ.get("PQ_ABL_OPTS", "").split(",")):      # e.g. PQ_ABL_OPTS=PQ_SP256_P3=0
+    _pqlib.set_option(*kv.split("="))
 import time
 t0 = time.time()
 while time.time() - t0 < 1.5:
     pq.qlinear_s8(xq, xs, wq, ws, None, torch.bfloat16, out=out)
-stamps = torch.zeros(256 * 8 * 4 * 2, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(NT * 8 * 4 * 2, dtype=torch.int64, device="cuda")
 _pqlib.lib().pq_dev_set_stamp_buffer(ctypes.c_void_p(stamps.data_ptr()))
 for flags in [int(a) for a in sys.argv[1:]] or [0, 1024, 8, 1, 2, 3, 4, 12, 32, 64]:
     os.environ["PQ_GEMM_DBG"] = str(flags)
@@ -31,7 +36,7 @@ for flags in [int(a) for a in sys.argv[1:]] or [0, 1024, 8, 1, 2, 3, 4, 12, 32, 
     torch.cuda.synchronize()
     line = f"flags={flags:4d} {'+'.join(names) or 'product':22s} median {med:6.1f} us  min {mn:6.1f} us"
     if flags:
-        st = stamps.cpu().numpy().reshape(256, 8, 4, 2).astype(np.float64)
+        st = stamps.cpu().numpy().reshape(NT, 8, 4, 2).astype(np.float64)
         rt, cy = st[..., 0] * 0.01, st[..., 1]            # us (100 MHz), shader cycles
         t00 = rt[:, :, 0].min()
         has3 = (st[:, :, 3, 0] > 0).all()
@@ -40,4 +45,9 @@ for flags in [int(a) for a in sys.argv[1:]] or [0, 1024, 8, 1, 2, 3, 4, 12, 32, 
                  + (f" | epilogue issue {pr(rt[:, :, 3] - rt[:, :, 2])} us | last stamp at {(rt[:, :, 3].max() - t00):6.2f} us" if has3 else f" | loop end at {(rt[:, :, 2].max() - t00):6.2f} us")
                  + f"\n      K-loop cycles {np.median(cy[:, :, 2] - cy[:, :, 1]):9.0f}  in-loop clock {np.median((cy[:, :, 2] - cy[:, :, 1]) / np.maximum(rt[:, :, 2] - rt[:, :, 1], 1e-9)) / 1e3:.3f} GHz"
                  + f"  prologue cycles {np.median(cy[:, :, 1] - cy[:, :, 0]):7.0f}" + (f"  epilogue cycles {np.median(cy[:, :, 3] - cy[:, :, 2]):7.0f}" if has3 else ""))
+        if NT > 256 and has3:        # multi-round grid: how the rounds line up (entry times of the blocks, per-block total)
+            ent = np.sort(rt[:, 0, 0] - t00)
+            tot = rt[:, :, 3].max(axis=1) - rt[:, :, 0].min(axis=1)
+            line += (f"\n      blocks {NT}: entry times of block #256/#512/#768/last: " + " / ".join(f"{ent[min(i, NT - 1)]:.1f}" for i in (256, 512, 768, NT - 1))
+                     + f" us;  per-block entry->epilogue issued: median {np.median(tot):.2f} us [{tot.min():.2f} .. {tot.max():.2f}]")
     print(line, flush=True)
