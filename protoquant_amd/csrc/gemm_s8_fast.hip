@@ -8,8 +8,10 @@
 //   * wave (wp, wq) = (w>>2, w&3) owns n-range wp*128+[0,128) x m-range wq*64+[0,64), split in
 //     halves hP (64 n) x hQ (32 m): four quadrants of 16 MFMAs.  (A 32x32x32 form of the same kernel held a
 //     lower clock, 1.74 vs 2.07 GHz in a bare MFMA loop, and ran 13 % slower: removed in round 2.)
-//   * LDS: a ring of K-tiles {P half0, P half1, Q half0, Q half1}: 2 x 64 KiB for the 256 x 256 tile, 3 x 48 KiB for
-//     the 128-row tile, one __shared__ array.  A half-tile is [rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
+//   * LDS: the 256 x 256 tile keeps SPLIT rings — three 32-KiB slots of weight (P) half-tiles, two of activation (Q) half-tiles,
+//     160 KiB (template flag P3; a weight piece, which comes from HBM inside a model, gets two K-tiles to land) — the other tiles a
+//     ring of whole K-tiles {P half0, P half1, Q half0, Q half1}: 3 x 48 KiB for the 128-row tile (2 x 64 KiB: the 256-row tile
+//     with P3 = false).  One __shared__ array.  A half-tile is [rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)
 //     (measured conflict-free for ds_read_b128 with both MFMA shapes).  Staging is
 //     global_load_lds_dwordx4: the LDS image is lane-linear, the XOR goes on the per-lane SOURCE address.
 //   * ONE s_barrier per K-tile (a barrier round trip costs ~130-150 cycles on this chip, measured; an
@@ -18,8 +20,8 @@
 //     quadrant q.  The barrier sits mid-tile (between quadrants 1 and 2): by then every wave has
 //     issued+retired its last read of tile t (so tile t's buffer can be refilled with tile t+2) and
 //     has waited for its own DMA pieces of tile t+1 (so tile t+1 is visible to all after the barrier).
-//     Every DMA therefore has a whole K-tile of MFMA time (~2000 cycles) to land.
-//   * Epilogue (gemm_epilogue.h, epi_staged_block): the tile's scales are DMA'd to LDS in the prologue; QSPEC E1-E4 in
+//     Every DMA therefore has a whole K-tile of MFMA time to land (the P pieces of the split rings: two).
+//   * Epilogue (gemm_epilogue.h, epi_staged_block): the tile's scales are DMA'd to LDS (prologue; split rings: tile NT-3); QSPEC E1-E4 in
 //     registers; the tile is transposed through a wave-private, XOR-swizzled region of the ring slot that the last K-tile
 //     does NOT occupy (no barrier: every wave is past the barrier that freed it) and written with 16-byte stores as
 //     256-byte row segments.

@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3i
-timeout 900 python3 tools/race_screen.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3i/race.txt | tail -25
-timeout 900 python3 tools/fuzz_variants.py 2>&1 | grep -v amdgpu.ids | tail -6 | tee gpurun_out/r3i/fuzz.txt
-cp protoquant_amd/libpq_hip.so /tmp/libpq_p2.so
-for rot in 1 24; do
-timeout 600 python3 tools/ab_gemm.py p3=protoquant_amd/libpq_hip.so p2=/tmp/libpq_p2.so@PQ_SP256_P3=0 --shapes 4096x4096x4096,4096x6144x4096,4096x4096x14336,4096x28672x4096 --rotate-weights $rot --per-graph 24 --rounds 11 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r3i/ab_p3.txt
-done
+mkdir -p gpurun_out/r3m
+for i in 6 10 16 24; do cp protoquant_amd/libpq_hip.so /tmp/libpq_pf$i.so; done
+for rot in 24 1; do
+echo "== rotate $rot"
+timeout 600 python3 tools/ab_gemm.py pf0=protoquant_amd/libpq_hip.so pf6=/tmp/libpq_pf6.so@PQ_RING_PF=6 pf10=/tmp/libpq_pf10.so@PQ_RING_PF=10 pf16=/tmp/libpq_pf16.so@PQ_RING_PF=16 pf24=/tmp/libpq_pf24.so@PQ_RING_PF=24 --shapes 4096x1024x28672,512x4096x4096,1024x4096x4096,4096x1024x8192 --rotate-weights $rot --per-graph 24 --rounds 9 2>&1 | grep -v amdgpu.ids
+done | tee gpurun_out/r3m/ring_pf.txt
