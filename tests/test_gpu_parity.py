@@ -303,6 +303,28 @@ def test_tail_split_bit_identical(pq, M, N, K, code, bias, pq_opt):
     same(pq.qlinear_s8(*args), want, "single-launch y")
 
 
+@pytest.mark.parametrize("M,N,K,code,bias", [(512, 512, 128, 0, True), (512, 768, 256, 1, False), (300, 520, 384, 0, True), (1000, 777, 512, 2, True),
+                                              (768, 1024, 640, 0, False), (1024, 512, 4096, 0, True), (257, 255, 1152, 1, True)])
+def test_split_rings_bit_identical(pq, M, N, K, code, bias, pq_opt):
+    """The 256 x 256 tile with split LDS rings (weights three slots deep, activations two: the default) against the same tile with the
+    2-deep ring of whole K-tiles (PQ_SP256_P3=0), rings of 1 to 32 K-tiles, ragged edges, every output dtype: both == the oracle."""
+    rng = np.random.default_rng(M * 3 + N * 5 + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
+    acc = (a.astype(np.int32) @ b.astype(np.int32).T)
+    want = Q.epilogue(acc, xs, ws, bv, code)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    args = (ta, torch.from_numpy(xs).cuda(), tb, torch.from_numpy(ws).cuda(), to_gpu(bv, code) if bias else None, TD[code])
+    pq_opt("PQ_FORCE_VARIANT", "sp256_16")
+    same(pq.qlinear_s8(*args), want, "split rings y")
+    same(pq.int_mm(ta, tb), acc, "split rings acc")
+    same(pq.qlinear_s8_t(*args).t().contiguous(), want, "split rings y^T")
+    pq_opt("PQ_SP256_P3", "0")
+    same(pq.qlinear_s8(*args), want, "2-deep ring y")
+    same(pq.int_mm(ta, tb), acc, "2-deep ring acc")
+
+
 def test_splitk_workspace_too_small_is_an_error(pq):
     from protoquant_amd import _lib
     L = _lib.lib()
