@@ -502,6 +502,42 @@ def run_llama70b_shard(args):
     ts.sort()
     dt = ts[len(ts) // 2]
     ops = L * 2.0 * M * (n_qkv * H + n_o * H + n_gu * H + n_down * I) + 2.0 * M * n_head * H
+    # Extra key — the ROW-SHARDED PAIRING of SURVEY section 8(f)4 (RowShardedQLinear / ShardedGatedMLP): o and down take the LOCAL shard of
+    # their producer's output (this rank's heads / intermediate channels) against the matching K-slice of the weight and emit f32 partials
+    # [M, H] for a reduce-scatter; no gather sits between gate/up and down, and silu*mul is fused into the local quantisation.  Same int8 ops
+    # per rank, GEMM shapes 4096 x 8192 x 1024 and 4096 x 8192 x 3584 instead of the 1024-wide column shards.
+    pairing = None
+    try:
+        rl = [(mkq(H, H // G), mkq(H, I // G)) for _ in range(2)]
+        x_a = torch.randn(M, H // G, device=dev).to(torch.bfloat16)          # stands for this rank's heads of the attention output
+
+        def fwd_row():
+            for l in range(L):
+                qkv, _o, gu, _d = layers[l & 1]
+                o_r, d_r = rl[l & 1]
+                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
+                xa = pq.quantize(x_a)
+                pq.qlinear_s8(xa.int_data, xa.scale, o_r.wq, o_r.ws, None, torch.float32)
+                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(I // G, dim=-1)
+                hq = pq.silu_mul_quantize(g_, u_)
+                pq.qlinear_s8(hq.int_data, hq.scale, d_r.wq, d_r.ws, None, torch.float32)
+            return head(x_h)
+        fwd_row(); torch.cuda.synchronize()
+        tr = []
+        for _ in range(3):
+            t0 = time.perf_counter(); fwd_row(); torch.cuda.synchronize()
+            tr.append(time.perf_counter() - t0)
+        dr = sorted(tr)[1]
+        # per layer two exchanges: reduce-scatter of the f32 partials [M, H] + all-gather of the bf16 row blocks (the next column-sharded
+        # linear wants the activation replicated): a rank moves 7/8 of M*H*4 + 7/8 of M*H*2 bytes each time
+        moved = L * 2 * (G - 1) / G * (M * H * 4 + M * H * 2) + 2.0 * M * V * (G - 1) / G
+        pairing = {"ms_per_step": round(dr * 1e3, 3), "value": round(ops / dr / 1e12, 2), "unit": "TOPS",
+                   "gemm_shapes": f"4096x{n_qkv}x8192 (fused qkv, column), 4096x8192x{H // G} (o, row), 4096x{n_gu}x8192 (fused gate+up, column), 4096x8192x{I // G} (down, row)",
+                   "modelled_exchange_ms": round(moved / (7 * 153e9) * 1e3, 2),
+                   "model": "per layer 2 x (reduce-scatter of f32 partials [M,H] + all-gather of bf16 row blocks), 7 xGMI links x 153 GB/s; NOT measured"}
+        del rl
+    except Exception as e:      # an extra figure must never lose the main line
+        print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
     # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
     gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
     t_gather = gathered * (G - 1) / G / (7 * 153e9)
@@ -511,7 +547,7 @@ def run_llama70b_shard(args):
                       "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
                                              f"4096x{n_o}x8192 (o), 4096x{n_gu}x8192 (fused gate+up), 4096x{n_down}x28672 (down), 4096x{n_head}x8192 (lm_head) (BASELINE configs[4])",
                                  "int8_ops_per_rank": ops, "gathered_bytes_per_pass": gathered,
-                                 "modelled_allgather_ms": round(t_gather * 1e3, 2),
+                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing,
                                  "model": "all-gather after dequant of every linear's bf16 output; a rank receives 7/8 of it over 7 xGMI links x 153 GB/s (fully connected, direct); NOT measured"},
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
