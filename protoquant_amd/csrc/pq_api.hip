@@ -79,11 +79,28 @@ struct Options {
 };
 Options g_opt;
 std::once_flag g_opt_once;
+// every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+                                    "PQ_SP256_P3", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_SKINNY_RB"};
+bool apply_option(const char* name, const char* value) {
+    if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
+    else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
+    else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
+    else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
+    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_SP256_P3")) pq::set_sp256_p3(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
+    else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
+    else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
+    else return false;
+    return true;
+}
 const Options& options() {
     std::call_once(g_opt_once, [] {
-        g_opt.variant = parse_variant(getenv("PQ_FORCE_VARIANT"));
-        g_opt.no_tailsplit = getenv("PQ_NO_TAILSPLIT") != nullptr;
-        g_opt.no_splitk = getenv("PQ_NO_SPLITK") != nullptr;
+        for (const char* n : kOptionNames)
+            if (const char* v = getenv(n)) apply_option(n, v);
         if (const char* r = getenv("PQ_ROCTX")) {
             if (*r && *r != '0') {
                 void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
@@ -95,7 +112,6 @@ const Options& options() {
                 }
             }
         }
-        if (const char* e = getenv("PQ_SKINNY_RB")) pq::set_skinny_rb(*e == '2' ? 2 : (*e == '1' ? 1 : 0));
     });
     return g_opt;
 }
@@ -208,18 +224,7 @@ int32_t pq_version(void) { return PQ_ABI_VERSION; }
 int32_t pq_set_option(const char* name, const char* value) {
     if (!name) return fail(PQ_ERR_BAD_ARG, "pq_set_option: null name");
     options();                                   // the environment is consumed first, so a later call_once cannot undo this
-    if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
-    else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
-    else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
-    else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
-    else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
-    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
-    else if (!strcmp(name, "PQ_SP256_P3")) pq::set_sp256_p3(!(value && *value == '0'));
-    else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
-    else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
-    else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
-    else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
-    else return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
+    if (!apply_option(name, value)) return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
     return PQ_OK;
 }
 const char* pq_last_error(void) { return g_err; }
