@@ -134,6 +134,11 @@ int32_t pq_selftest_fast_quotient(const uint32_t* x_bits, const uint32_t* s_bits
  * checked, counts[1] += pairs whose code differs from clamp(rne(x / s)).  counts[2] must be zeroed by the caller.  QSPEC Q4. */
 int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void* stream);
 
+/* Self-test hook: every 16-bit pattern g with 0 < |g| <= 86 (the domain of the division-free silu of bf16 / fp16 rows) through the
+ * one-correction division the producer kernel uses, the two-correction form and true division.  counts[0] += patterns, counts[1] +=
+ * patterns whose stored silu(g) differs between the first two, counts[2] += between the last two.  counts[3] zeroed by the caller.  QSPEC S4. */
+int32_t pq_selftest_silu_short(int32_t dtype, unsigned long long* counts, void* stream);
+
 /* Name of the GEMM kernel variant the dispatcher would pick for this problem (static string). */
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 

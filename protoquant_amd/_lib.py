@@ -18,7 +18,7 @@ _DT = {torch.bfloat16: PQ_BF16, torch.float16: PQ_FP16, torch.float32: PQ_F32}
 EXPORTS = (
     "pq_version", "pq_last_error", "pq_quant_rowwise", "pq_quant_colwise", "pq_dequant",
     "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes", "pq_gemm_variant_name",
-    "pq_selftest_fast_quotient", "pq_selftest_half_encode", "pq_qlinear_dyn", "pq_qlinear_dyn_workspace_bytes", "pq_silu_mul_quant_rowwise",
+    "pq_selftest_fast_quotient", "pq_selftest_half_encode", "pq_selftest_silu_short", "pq_qlinear_dyn", "pq_qlinear_dyn_workspace_bytes", "pq_silu_mul_quant_rowwise",
     "pq_rmsnorm_quant_rowwise", "pq_set_option", "pq_qlinear_s8_t", "pq_qlinear_t_workspace_bytes",
 )
 
@@ -74,6 +74,8 @@ def lib() -> ctypes.CDLL:
     L.pq_selftest_fast_quotient.argtypes = [vp, vp, i64, vp, vp]
     L.pq_selftest_half_encode.restype = i32
     L.pq_selftest_half_encode.argtypes = [i32, vp, vp]
+    L.pq_selftest_silu_short.restype = i32
+    L.pq_selftest_silu_short.argtypes = [i32, vp, vp]
     if L.pq_version() != ABI_VERSION:
         raise PQError(f"libpq_hip.so ABI {L.pq_version()} != expected {ABI_VERSION}")
     _lib = L

@@ -33,6 +33,7 @@ void set_silu_tpr(int);
 void set_rms_wave_max(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 void launch_half_encode_check(int, unsigned long long*, hipStream_t);
+void launch_silu_short_check(int, unsigned long long*, hipStream_t);
 }  // namespace pq
 
 namespace {
@@ -451,6 +452,12 @@ int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void*
     if (!counts || (dtype != PQ_BF16 && dtype != PQ_FP16)) return fail(PQ_ERR_BAD_ARG, "pq_selftest_half_encode: dtype must be bf16 or fp16, counts non-null");
     pq::launch_half_encode_check(dtype, counts, static_cast<hipStream_t>(stream));
     return check_launch("pq_selftest_half_encode");
+}
+
+int32_t pq_selftest_silu_short(int32_t dtype, unsigned long long* counts, void* stream) {
+    if (!counts || (dtype != PQ_BF16 && dtype != PQ_FP16)) return fail(PQ_ERR_BAD_ARG, "pq_selftest_silu_short: dtype must be bf16 or fp16, counts non-null");
+    pq::launch_silu_short_check(dtype, counts, static_cast<hipStream_t>(stream));
+    return check_launch("pq_selftest_silu_short");
 }
 
 #ifdef PQ_ABLATION_BUILD

@@ -50,7 +50,12 @@ template <> struct Pair<PQ_FP16> {
 //    scaling).  Waves holding a zero (whose sign the residual steps would lose), |g| > 86, Inf or NaN take the `/` path
 //    (silu_fast_div_ok, decided once per wave).
 // Returns the products BEFORE their storage rounding.
-template <int DT, bool FASTDIV, int NP>
+//  - SHORT (16-bit storage only): silu(g) is rounded to the storage format before the product, and g itself is a 16-bit value, so
+//    the stored silu(g) is a function of 65 536 inputs.  On ALL of the fast-division domain ONE residual correction on the raw rcp
+//    (q = g*y0; e = fma(-d, q, g); q = fma(e, y0, q)) rounds to the same stored value as the correctly rounded quotient — enumerated on
+//    the GPU (pq_selftest_silu_short, tests/test_gpu_parity.py::test_silu_short_division_whole_domain); the Newton step and the second
+//    correction (4 of ~40 VALU results per element) are dropped for bf16 / fp16 rows.
+template <int DT, bool FASTDIV, int NP, bool SHORT = false>
 __device__ __forceinline__ void silu_mul_stage(const v2f (&g)[NP], const v2f (&u)[NP], v2f (&h)[NP]) {
     v2f tc[NP], n[NP], r[NP], p[NP], d[NP], sg[NP];
 #pragma unroll
@@ -73,7 +78,17 @@ __device__ __forceinline__ void silu_mul_stage(const v2f (&g)[NP], const v2f (&u
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) d[k] = splat(1.0f) + v2f{__builtin_ldexpf(p[k].x, (int)n[k].x), __builtin_ldexpf(p[k].y, (int)n[k].y)};
-    if constexpr (FASTDIV) {
+    if constexpr (FASTDIV && SHORT) {
+        v2f y0[NP], q[NP], e[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) y0[k] = v2f{__builtin_amdgcn_rcpf(d[k].x), __builtin_amdgcn_rcpf(d[k].y)};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) q[k] = g[k] * y0[k];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) e[k] = pk_fma(-d[k], q[k], g[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sg[k] = pk_fma(e[k], y0[k], q[k]);
+    } else if constexpr (FASTDIV) {
         v2f y0[NP], y[NP], q[NP], e[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) y0[k] = v2f{__builtin_amdgcn_rcpf(d[k].x), __builtin_amdgcn_rcpf(d[k].y)};
@@ -132,7 +147,7 @@ template <int DT> __device__ __forceinline__ bool silu_fast_div_ok(uint32_t mn, 
 }
 
 // one 16-byte vector of g and of u -> one 16-byte vector of h in the storage dtype
-template <int DT, bool FASTDIV>
+template <int DT, bool FASTDIV, bool SHORT = (DT != PQ_F32)>
 __device__ __forceinline__ v4u silu_mul_vec(const v4u& gv, const v4u& uv) {
     constexpr int NP = DT == PQ_F32 ? 2 : 4;
     v2f g[NP], u[NP], h[NP];
@@ -149,7 +164,7 @@ __device__ __forceinline__ v4u silu_mul_vec(const v4u& gv, const v4u& uv) {
             u[j] = Pair<DT>::unpack(uw);
         }
     }
-    silu_mul_stage<DT, FASTDIV, NP>(g, u, h);
+    silu_mul_stage<DT, FASTDIV, NP, SHORT && DT != PQ_F32>(g, u, h);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         if constexpr (DT == PQ_F32) {
@@ -510,6 +525,27 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_generic(const void* __restr
     if (threadIdx.x == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
     for (int64_t c = threadIdx.x; c < cols; c += 256) qr[c] = (int8_t)code_of(Elem<DT>::to_f32(h_at(c)), s);
+}
+
+// dev/test kernel: every 16-bit pattern g of the fast-division domain (0 < |g| <= 86) through the three division forms, u = 1 (so h is the
+// stored silu(g)).  out[0] += patterns in the domain, out[1] += patterns whose SHORT result differs from the two-correction form,
+// out[2] += patterns whose two-correction form differs from true division.
+template <int DT>
+__global__ __launch_bounds__(256) void silu_short_check(unsigned long long* __restrict__ out) {
+    const uint32_t pat = blockIdx.x * 256u + threadIdx.x;            // 256 blocks x 256 threads = all 65 536 patterns
+    const uint32_t mag = pat & 0x7FFFu;
+    if (!silu_fast_div_ok<DT>(mag, mag)) return;
+    const uint32_t one = DT == PQ_BF16 ? 0x3F80u : 0x3C00u;
+    const v4u gv = v4u{pat | (pat << 16), pat | (pat << 16), pat | (pat << 16), pat | (pat << 16)};
+    const v4u uv = v4u{one | (one << 16), one | (one << 16), one | (one << 16), one | (one << 16)};
+    const v4u a = silu_mul_vec<DT, true, true>(gv, uv), b = silu_mul_vec<DT, true, false>(gv, uv), c = silu_mul_vec<DT, false, false>(gv, uv);
+    atomicAdd(&out[0], 1ull);
+    if (a[0] != b[0]) atomicAdd(&out[1], 1ull);
+    if (b[0] != c[0]) atomicAdd(&out[2], 1ull);
+}
+void launch_silu_short_check(int dtype, unsigned long long* out, hipStream_t st) {
+    if (dtype == PQ_BF16) silu_short_check<PQ_BF16><<<dim3(256), dim3(256), 0, st>>>(out);
+    else silu_short_check<PQ_FP16><<<dim3(256), dim3(256), 0, st>>>(out);
 }
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }

@@ -419,6 +419,19 @@ def test_half_encode_whole_domain(pq, dtype_code, name, min_pairs):
     assert pairs > min_pairs and bad == 0, f"{name}: {pairs} pairs, {bad} mismatches"
 
 
+@pytest.mark.parametrize("dtype_code,name,min_patterns", [(0, "bf16", 30000), (1, "fp16", 40000)])
+def test_silu_short_division_whole_domain(pq, dtype_code, name, min_patterns):
+    """bf16 / fp16 rows of silu(g)*u take ONE residual correction on the raw reciprocal (producer_kernels.hip: SHORT).  The stored silu(g)
+    is a function of the 16-bit g alone: every pattern of the fast-division domain (0 < |g| <= 86) is enumerated on the GPU through the
+    short form, the two-correction form and true division — all three must store the same value."""
+    from protoquant_amd import _lib
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().pq_selftest_silu_short(dtype_code, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    n, bad_short, bad_two = out.tolist()
+    assert n > min_patterns and bad_short == 0 and bad_two == 0, f"{name}: {n} patterns, {bad_short} / {bad_two} mismatches"
+
+
 def test_column_sharded_world1_matches_unsharded(pq):
     """ColumnShardedQLinear over RCCL (backend nccl) with a 1-rank group == plain qlinear, bit for bit."""
     import torch.distributed as dist
