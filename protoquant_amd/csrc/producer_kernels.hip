@@ -58,6 +58,18 @@ template <> struct Pair<PQ_FP16> {
 template <int DT, bool FASTDIV, int NP, bool SHORT = false>
 __device__ __forceinline__ void silu_mul_stage(const v2f (&g)[NP], const v2f (&u)[NP], v2f (&h)[NP]) {
     v2f tc[NP], n[NP], r[NP], p[NP], d[NP], sg[NP];
+    if constexpr (FASTDIV && SHORT && DT == PQ_BF16) {
+        // bf16 rows on the fast-division domain: 1 + exp(-g) from the hardware's exp2 (v_exp_f32, ~1 ulp).  The STORED silu(g) is a function of
+        // the 16-bit g alone, and on every one of the 34 136 patterns of the domain this sequence stores the value the specified polynomial
+        // exponential + correctly rounded quotient store (tools/ubench/silu_variants enumerates the candidates; pq_selftest_silu_short
+        // re-checks the shipped one on the GPU it runs on).  Fourteen VALU results per element fewer.  (fp16 keeps the polynomial: with its
+        // 11-bit significand two patterns differ.)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const v2f a = g[k] * splat(-__builtin_bit_cast(float, 0x3FB8AA3Bu));          // -g * log2(e)
+            d[k] = splat(1.0f) + v2f{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < NP; ++k) tc[k] = v2f{__builtin_amdgcn_fmed3f(-g[k].x, -30.0f, 100.0f), __builtin_amdgcn_fmed3f(-g[k].y, -30.0f, 100.0f)};
 #pragma unroll
@@ -78,6 +90,7 @@ __device__ __forceinline__ void silu_mul_stage(const v2f (&g)[NP], const v2f (&u
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) d[k] = splat(1.0f) + v2f{__builtin_ldexpf(p[k].x, (int)n[k].x), __builtin_ldexpf(p[k].y, (int)n[k].y)};
+    }
     if constexpr (FASTDIV && SHORT) {
         v2f y0[NP], q[NP], e[NP];
 #pragma unroll
