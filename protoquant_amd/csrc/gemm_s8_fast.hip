@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
     constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
     const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;
-    // the staged epilogue reads the scale vectors 16 bytes at a time (LDS image filled by DMA, or — P3 — registers filled in the last K-tile)
+    // the staged epilogue reads the scale vectors 16 bytes at a time from an LDS image filled by DMA (scale_dma below)
     const bool scales_ok = (OUT == OUT_I32) ||
         ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
     // Where the tile's 256 row scales and 256 column scales sit in LDS for the epilogue (1 KiB each, by DMA).  P3 has no LDS of its
