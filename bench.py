@@ -578,9 +578,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "tp":      # (--mode tp at world 1: the whole tp step — graph-captured RCCL exchange included — on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
         else:
@@ -597,7 +600,7 @@ def main():
     # bf16 output shards per step (strong scaling: the whole job is ONE M x N x K qlinear).  --mode dp: every rank runs
     # the whole qlinear on its own batch (weak scaling, no collective); reported as the extra key "dp" in tp runs.
     mode = args.mode if args.mode != "auto" else ("tp" if world > 1 else "dp")
-    tp = mode == "tp" and world > 1
+    tp = mode == "tp"
     st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
 
     def build_step(tp_mode):
@@ -640,6 +643,8 @@ def main():
                 if int(ok.item()) == 0:
                     rg = None
             if rg is not None:
+                info["native"] = True
+
                 def gather():
                     rg.gather_into(y, y_full, N)
             else:
@@ -658,28 +663,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the step.  Compute (K1 + K3/K4) is replayed from a hipGraph of S steps (host-independent); the collective of a tp
-    # step is issued eagerly behind each step's compute (S = 1 there).
+    # ---- the step.  Everything is replayed from a hipGraph of S steps (host-independent): K1 + K3/K4 and, in a tp step, the exchange as
+    # well — RCCL collectives are capturable, and a ~60 us step issued collective by collective from Python would time the host, not
+    # xGMI.  Only if that capture fails (or the exchange goes through torch.distributed) is the collective issued eagerly behind each
+    # step's compute graph; the line says which, and carries the host time per step next to the device time either way.
     K_steps = max(1, args.steps)
     use_graph = not args.no_graph
-    S = 1 if tp else min(K_steps, 50)
     g_main = g_rem = None
-    if use_graph:
+    coll_in_graph = False
+    if tp and use_graph and xinfo.get("native"):
         try:
-            g_main = graph_of(lambda: (k1(), k3()), S)
+            gather(); torch.cuda.synchronize()                 # (allocates the exchange workspace outside the capture)
+            S = min(K_steps, 20)
+            g_main = graph_of(lambda: (k1(), k3(), gather()), S)
             if K_steps % S:
-                g_rem = graph_of(lambda: (k1(), k3()), K_steps % S)
-        except Exception as e:   # report, never silently change what is measured
-            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
+                g_rem = graph_of(lambda: (k1(), k3(), gather()), K_steps % S)
+            coll_in_graph = True
+        except Exception as e:
+            print(f"[bench] capturing the RCCL exchange into the step graph failed ({e}); collective issued eagerly behind each step", file=sys.stderr)
             g_main = g_rem = None
+        if dist is not None:                                   # every rank must replay the same thing
+            ok = torch.tensor([1 if coll_in_graph else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            coll_in_graph = bool(int(ok.item()))
+            if not coll_in_graph:
+                g_main = g_rem = None
+    if not coll_in_graph:
+        S = 1 if tp else min(K_steps, 50)
+        if use_graph:
+            try:
+                g_main = graph_of(lambda: (k1(), k3()), S)
+                if K_steps % S:
+                    g_rem = graph_of(lambda: (k1(), k3()), K_steps % S)
+            except Exception as e:   # report, never silently change what is measured
+                print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
+                g_main = g_rem = None
+    whole_step_in_graph = g_main is not None and (not tp or coll_in_graph)
 
     def run_steps(n):
         """exactly n steps"""
-        if g_main is not None and not tp:
+        if whole_step_in_graph:
             for _ in range(n // S):
                 g_main.replay()
             if n % S:
-                (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(lambda: (k1(), k3()), n % S)).replay()
+                fn = (lambda: (k1(), k3(), gather())) if tp else (lambda: (k1(), k3()))
+                (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(fn, n % S)).replay()
             return
         for _ in range(n):
             if g_main is not None:
@@ -702,11 +730,12 @@ def main():
     # ---- timed: R blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; per block the MAX over
     # ranks; the reported step time is the MEDIAN block (min and max are reported too)
     R = max(1, args.repeats)
-    blocks = []
+    blocks, host_enq = [], []
     for _ in range(R):
         fence()
         t0 = time.perf_counter()
         run_steps(K_steps)
+        host_enq.append(time.perf_counter() - t0)          # host time to ENQUEUE the block (the device may still be running)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -786,10 +815,42 @@ def main():
         k1_big = {"rows": Mb, "cols": K, "avg_kernel_us": round(tb, 2), "achieved": round((3 * Mb * K + 4 * Mb) / tb / 1e3, 1), "unit": "GB/s",
                   "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4), "how": "three rotating 16384 x 4096 inputs (576 MiB per round): HBM-fed"}
         del bigs, gb_
-    if tp:
+    # tp: the exchange (collective + layout pass) by itself, gap-free from its own graph when it is capturable, else eager launches between
+    # events; every rank runs it in step (a collective), the MAX over ranks is reported
+    t_exch = None
+    if tp and gather is not None:
+        fence()
+        try:
+            if coll_in_graph:
+                g_ex = graph_of(gather, PG)
+                g_ex.replay(); fence()
+                v = med([ev_us(g_ex, PG) for _ in range(9)])
+            else:
+                def ex_eager():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(PG):
+                        gather()
+                    b.record(); b.synchronize()
+                    return a.elapsed_time(b) * 1e3 / PG
+                ex_eager(); fence()
+                v = med([ex_eager() for _ in range(9)])
+            tt = torch.tensor([v], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_exch = float(tt.item())
+        except Exception as e:
+            print(f"[bench] exchange-only timing failed: {e}", file=sys.stderr)
         fence()
     consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)       # cache-hot K1 <= in-step K1 <= HBM-cold K1
-    assert consistent or args.no_consistency_check or args.share_gpu, \
+    host_us = sorted(host_enq)[len(host_enq) // 2] / K_steps * 1e6
+    step_us = dt / K_steps * 1e6
+    # a step that is not replayed whole from a graph is only a device measurement while the host enqueues faster than the device runs
+    host_bound = (not whole_step_in_graph) and host_us > 0.9 * step_us
+    if host_bound:
+        print(f"[bench] WARNING: host-bound step: enqueueing takes {host_us:.1f} us per step, the step {step_us:.1f} us — this line times Python, not the device", file=sys.stderr)
+        consistent = False
+    assert consistent or host_bound or args.no_consistency_check or args.share_gpu, \
         f"inconsistent timings: GEMM {t_gemm:.2f} us + K1 {t_k1_hot:.2f} (cache-resident) .. {t_k1:.2f} us (HBM) vs compute step {t_stepc:.2f} us"
 
     ops_job = 2.0 * M * N * K * (1 if tp else world)       # whole job per step
@@ -811,7 +872,8 @@ def main():
         "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
                    "parallelism": (f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant"
                                    if tp else f"dp{world} over tokens, replicated int8 weights, no collective"),
-                   "launch": (f"hipgraph x{S} steps/replay" + (", collective eager behind each step" if tp else "") if g_main is not None else "eager"),
+                   "launch": (f"hipgraph x{S} steps/replay" + ((", RCCL exchange captured in the graph" if coll_in_graph else ", collective eager behind each step") if tp else "") if g_main is not None else "eager"),
+                   "collective_in_graph": (coll_in_graph if tp else None),
                    "repeats": R, "timed": f"median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks)",
                    "warmup_seconds": args.warmup_seconds, "gemm_variant": variant, **xinfo},
         "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
@@ -828,13 +890,25 @@ def main():
                        "in_step_us": round(t_stepc - t_gemm, 2), "cache_resident_replay_us": round(t_k1_hot, 2),
                        "same_kernel_4x_rows": k1_big},
         "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
+        "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool(host_bound),
     }
+    if tp:
+        # compute and exchange of the tp step, separately (per rank; device time): K1 (replicated) + the local GEMM, and the all-gather
+        # + layout pass.  compute_us + exchange_us ~ the step: the exchange is not overlapped in this form.
+        out["compute_us"] = round(t_stepc, 2)
+        out["exchange_us"] = round(t_exch, 2) if t_exch is not None else None
+        out["exchange_bytes_received_per_rank"] = 2 * M * (N - n_local)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj) and not tp:
+    if os.path.exists(tj):
         try:
             tr = json.load(open(tj))
-            out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = tr.get("source")
+            if (M, n_local, K) == (4096, 4096, 4096):
+                out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = tr.get("source")
+            else:       # tp: the rank's shard GEMM is another shape: PMC passes per shard width, where collected
+                by = tr.get("gemm_hbm_bytes_per_launch_by_shape", {})
+                out["roofline"]["traffic"] = by.get(f"{M}x{n_local}x{K}")
+                out["roofline"]["traffic_source"] = tr.get("source_by_shape") if out["roofline"]["traffic"] else None
         except Exception:
             pass
     if tp and args.tp_transposed_leg and xinfo.get("exchange", "").startswith("libpq_rccl"):

@@ -18,6 +18,13 @@ struct EpiArgs {
 // The transposed product y^T = Wq . xq^T (pq_qlinear_s8_t: the GEMM's rows are output channels n, its columns tokens m) must
 // still round as QSPEC E2-E3 say — the TOKEN scale first — so the column scale is applied first and the bias runs along rows.
 constexpr int32_t EPI_COL_FIRST = 1, EPI_BIAS_ROWS = 2;
+// The two bits only ever travel together: 0 (y = x.W^T: row scale first, bias along columns) or the transposed form (column scale
+// first; a bias, if any, along rows).  The staged epilogue dispatches on that pairing (PQ_EPI_STAGED_DISPATCH), the direct / split-K /
+// skinny / generic epilogues read the bits one by one: any other combination would round differently on interior and edge tiles, so
+// every launcher checks epi_flags_valid() (pq_api.hip: run_gemm) and nothing else constructs flags.
+constexpr bool epi_flags_valid(int32_t flags, bool has_bias) {
+    return flags == 0 || (flags == EPI_COL_FIRST && !has_bias) || (flags == (EPI_COL_FIRST | EPI_BIAS_ROWS) && has_bias);
+}
 
 template <int OUT> struct OutElem { using type = typename Elem<OUT>::store_t; };
 template <> struct OutElem<OUT_I32> { using type = int32_t; };

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "gemm_epilogue.h"
+#include "kloop_p3_asm.inc"   // generated: tools/gen_kloop_asm.py
 
 namespace pq {
 
@@ -104,7 +105,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // the launch.  Here a weight piece is issued TWO K-tiles before it is needed.  The activations were written by the previous
 // kernel and come from the Infinity Cache: one K-tile of lead is enough for them.  No LDS of their own is left for the scale vectors:
 // they are DMA'd, two K-tiles before the epilogue, into the P slot that no later tile needs.
-template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false>   // ABL: compile-time ablation (0 = product)
+// ASMV (P3 only): K-tiles 1 .. NT-4 run in the hand-allocated asm statement kloop_p3_asm<ASMV> (kloop_p3_asm.inc) instead of the HIP loop.
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     static_assert(!LC || (TM == 128 && TN == 256), "loader / consumer split: 128 x 256 tile only");
     static_assert(!P3 || (TM == 256 && TN == 256 && !LC), "split rings: 256 x 256 tile only");
+    static_assert(ASMV == 0 || (P3 && (ABL == 0 || ABL == 1024)), "asm K-loop: split-ring tile only (dev builds: with stamps)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = LC && wave >= 4;
@@ -229,6 +232,16 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
                 for (int j = 0; j < NQJ; ++j)
 #pragma unroll
                     for (int r = 0; r < NACC; ++r) acc[a][b][i][j][r] = 0;
+    if constexpr (ASMV != 0) {   // keep the zeros in registers: folded into the C operand of the peeled tile 0, they cost that tile 64 more live registers (spills)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NQJ; ++j) asm volatile("" : "+v"(acc[a][b][i][j]));
+    }
 
     v4i fPa[NPI][NKS], fPb[NPI][NKS], fQa[NQJ][NKS], fQb[NQJ][NKS];
     if constexpr (DBG) {   // defined operands when LDS reads are ablated
@@ -462,12 +475,31 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     int kt = 0, slot = 0, qslot = 0;
     constexpr int DEPTH = P3 ? 3 : NBUF;      // tiles ahead of the current one whose (P-side) DMA is issued in it
     auto adv = [&]() { ++kt; slot = (slot + 1 == NPB) ? 0 : slot + 1; qslot = (qslot + 1 == NQB) ? 0 : qslot + 1; };
+    if constexpr (ASMV != 0) {
+        // Tile 0 (first-half prologue) in HIP, then tiles 1 .. NT-1 in the asm statement: it continues the HIP tile's protocol exactly
+        // (fPa / fQa hold tile 1's first fragments, gQ points at tile 3, gP at tile 4, the per-wave DMA issue order and the vmcnt
+        // counts are the HIP loop's), including the scale-vector DMA of tile NT-3.  The launcher sends only K >= 5 * 128 here.
+        {
+            tile(0, 0, 0, yes, yes, yes);
+            const uint32_t bp[2] = {smem_base + lP[0], smem_base + lP[1]};
+            const uint32_t bph[2] = {bp[0] + 2 * PB, bp[1] + 2 * PB};
+            const uint32_t bq[2] = {smem_base + QBASE + lQ[0], smem_base + QBASE + lQ[1]};
+            const int sbase = w == 0 ? m0 : n0, slim = w == 0 ? M : N;          // (scale_dma's source address)
+            int e0 = sbase + lane * 4;
+            e0 = e0 + 3 < slim ? e0 : (slim >= 4 ? slim - 4 : 0);
+            const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
+            const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok && w < 2));   // ("s" operands must be provably uniform)
+            kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
+                               (uint32_t)(wave >> 2), ssrc, smem_base + (uint32_t)w * 1024u, do_scales);
+        }
+    } else {
     while (kt + DEPTH < NT) { tile(kt, slot, qslot, yes, yes, yes); adv(); }
     if constexpr (DEPTH == 3) {
         if (kt + 2 < NT) { tile(kt, slot, qslot, yes, yes, no); adv(); }
     }
     if (kt + 1 < NT) { tile(kt, slot, qslot, yes, no, no); adv(); }
     tile(kt, slot, qslot, no, no, no);
+    }
 
     stamp(2);
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
@@ -583,6 +615,8 @@ int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(
 
 bool g_sp128_lc = true;     // loader / consumer split of the 128 x 256 tile (pq_set_option("PQ_SP128_LC", "0") restores the 8-wave form)
 void set_sp128_lc(bool v) { g_sp128_lc = v; }
+int g_sp256_asm = 1;        // K-loop variant of kloop_p3_asm.inc (pq_set_option("PQ_SP256_ASM", "n")); 0 = the HIP loop
+void set_sp256_asm(int v) { g_sp256_asm = v < 0 ? 1 : v; }
 bool g_sp256_p3 = true;     // split rings of the 256 x 256 tile: weights 3 slots deep (pq_set_option("PQ_SP256_P3", "0") restores the 2-deep ring)
 void set_sp256_p3(bool v) { g_sp256_p3 = v; }
 
@@ -599,6 +633,14 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     }
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && TM == 256 && TN == 256) {
+        if (g_sp256_p3 && gemm_debug_flags() == 1024) {      // stamps only, around an asm K-loop variant
+            switch (K >= 5 * FBK ? g_sp256_asm : 0) {
+#define PQ_ASMS(n) case n: gemm_s8_sp256<OUT, 1024, TM, TN, false, true, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1024, g_stamps, 1); return;
+                PQ_ASMS(1) PQ_ASMS(2)
+#undef PQ_ASMS
+                default: break;
+            }
+        }
         if (g_sp256_p3) {
             switch (gemm_debug_flags()) {
 #define PQ_ABL3(n) case n: gemm_s8_sp256<OUT, n, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
@@ -617,6 +659,17 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
 #endif
     if constexpr (TM == 256 && TN == 256) {
         if (g_sp256_p3) {
+            // K-tiles 1 .. NT-1 in the hand-allocated asm statement (kloop_p3_asm.inc, variant 1) whenever there are at least five K-tiles;
+            // PQ_SP256_ASM=0 keeps the HIP loop (same bits), 2 / 3 are the A/B and timing-only variants (bf16 output only)
+            const int av = K >= 5 * FBK ? g_sp256_asm : 0;
+            if (av == 1) {
+                gemm_s8_sp256<OUT, 0, TM, TN, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+                return;
+            }
+            if constexpr (OUT == PQ_BF16) {
+                if (av == 2) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+                if (av == 3) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 3><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+            }
             gemm_s8_sp256<OUT, 0, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
             return;
         }

@@ -35,8 +35,10 @@ class RMSNormQuant(nn.Module):
 
 
 class _FusedSlice(nn.Module):
-    """Projection number `index` of a FusedQLinear shared by sibling slices: the slice that sees a new input runs the fused
-    GEMM; its siblings, called with the SAME input object right after (as the attention code does), take their part of it."""
+    """Projection number `index` of a FusedQLinear shared by sibling slices.  The attention module's forward pre-hook (installed by
+    fuse_llama_layers) runs the fused GEMM ONCE per forward on the hidden states it is called with; the slices, called with that
+    same object by the stock attention code, return their parts of it.  Called with anything else (outside the attention forward, a
+    different tensor), a slice computes its result from its own input — correct, just not shared."""
 
     def __init__(self, shared: "_SharedFused", index: int):
         super().__init__()
@@ -48,19 +50,38 @@ class _FusedSlice(nn.Module):
 
 
 class _SharedFused(nn.Module):
+    """The fused q/k/v GEMM of one attention module and its per-forward result: begin() at the attention's entry, end() at its exit
+    (always: exceptions included), so nothing outlives the forward, a recomputed forward (activation checkpointing) recomputes, and
+    an input changed in place between two forwards is never served stale."""
+
     def __init__(self, fused: FusedQLinear):
         super().__init__()
         self.fused = fused
-        self._key, self._outs, self._left = None, None, 0
+        self._key, self._outs = None, None
+
+    def begin(self, x):
+        self._key, self._outs = x, self.fused(x)
+
+    def end(self):
+        self._key, self._outs = None, None
 
     def part(self, x, index):
-        if self._outs is None or self._key is not x:
-            self._key, self._outs, self._left = x, self.fused(x), len(self.fused.splits)
-        out = self._outs[index]
-        self._left -= 1
-        if self._left == 0:                 # every sibling served: drop the references
-            self._key, self._outs = None, None
-        return out
+        if self._outs is not None and self._key is x:
+            return self._outs[index]
+        return self.fused(x)[index]
+
+
+def _install_qkv_hooks(attn: nn.Module, shared: _SharedFused) -> None:
+    def pre(mod, args, kwargs):
+        x = kwargs.get("hidden_states", args[0] if args else None)
+        if x is not None:
+            shared.begin(x)
+
+    def post(mod, args, kwargs, out):
+        shared.end()
+
+    attn.register_forward_pre_hook(pre, with_kwargs=True)
+    attn.register_forward_hook(post, with_kwargs=True, always_call=True)
 
 
 def _is_rmsnorm(m) -> bool:
@@ -80,6 +101,7 @@ def fuse_llama_layers(model: nn.Module, fuse_norms: bool = True, fuse_qkv: bool 
         if fuse_qkv:
             attn.qkv_fused = _SharedFused(FusedQLinear([q, k, v]))
             attn.q_proj, attn.k_proj, attn.v_proj = (_FusedSlice(attn.qkv_fused, i) for i in range(3))
+            _install_qkv_hooks(attn, attn.qkv_fused)
         if fuse_norms and _is_rmsnorm(layer.input_layernorm):
             layer.input_layernorm = RMSNormQuant(layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
         mlp_ok = isinstance(mlp, GatedMLP) or all(isinstance(getattr(mlp, p, None), qlinear) for p in ("gate_proj", "up_proj"))

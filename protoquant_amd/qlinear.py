@@ -28,28 +28,29 @@ def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
     return acc
 
 
-_WORKSPACES: dict = {}
-_RETIRED: list = []        # buffers outgrown WHILE a hipGraph was being captured (the graph holds their address)
+_WORKSPACES: dict = {}     # (device, stream) -> [buffer, handed out under a hipGraph capture?]
+_RETIRED: list = []        # outgrown buffers whose address a captured hipGraph holds
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Caller-owned scratch (split-K slabs, the one-call path's codes and scales): one buffer per (device, stream) — reuse is
     ordered by the stream, and two streams never share a buffer.  It grows geometrically (at least 2x), so a run with rising M
-    reallocates O(log) times; an outgrown buffer is simply dropped — the caching allocator hands its memory out again in stream
-    order, which is safe because every use of it was enqueued on this stream before the free — unless a hipGraph capture is
-    in progress: a captured launch keeps the raw address, so that buffer is parked instead (clear_workspaces() releases all)."""
+    reallocates O(log) times.  An outgrown buffer is simply dropped — the caching allocator hands its memory out again in stream
+    order, which is safe because every use of it was enqueued on this stream before the free — UNLESS it was ever handed out while
+    a hipGraph was being captured (whether it was allocated during that capture or eagerly before it, the usual warm-up): a captured
+    launch keeps the raw address, so such a buffer is parked until clear_workspaces()."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
-        capturing = torch.cuda.is_current_stream_capturing()
-        if buf is not None and capturing:
-            _RETIRED.append(buf)
-        size = nbytes if buf is None else max(nbytes, 2 * buf.numel())
-        buf = torch.empty((size,), dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = buf
-        if capturing:
-            _RETIRED.append(buf)      # keep it alive as long as graphs may replay, even if a later call outgrows it
-    return buf
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = _WORKSPACES.get(key)
+    if ent is None or ent[0].numel() < nbytes:
+        if ent is not None and ent[1]:
+            _RETIRED.append(ent[0])
+        size = nbytes if ent is None else max(nbytes, 2 * ent[0].numel())
+        ent = [torch.empty((size,), dtype=torch.uint8, device=device), False]
+        _WORKSPACES[key] = ent
+    if capturing:
+        ent[1] = True          # graph-pinned from now on: replays write through this address
+    return ent[0]
 
 
 def clear_workspaces() -> None:

@@ -56,9 +56,20 @@ def convert_checkpoint(state_dict: dict, *, device="cuda", is_linear: Callable[[
       are replaced by one FusedQLinear entry.  gated_mlp: prefixes of modules with gate_proj / up_proj / down_proj children
       (-> ``<p>.gate_up.*``, ``<p>.down.*``).  column_sharded / row_sharded: linear prefixes stored as this rank's shard
       (``<p>.local.*``).  sharded_gated_mlp: MLP prefixes stored as ShardedGatedMLP (gate/up column shards fused, down row
-      shard with full-row scales).  Patterns may be exact prefixes or regular expressions (matched with re.fullmatch)."""
+      shard with full-row scales).  A pattern is a module prefix, compared LITERALLY ("model.layers.0.mlp": its dots are dots, a name
+      with brackets or a plus sign is fine), or a regular expression given explicitly: a compiled ``re.Pattern`` or a string that
+      starts with ``re:`` (matched with re.fullmatch)."""
     def match(patterns, name):
-        return any(p == name or re.fullmatch(p, name) for p in patterns)
+        for p in patterns:
+            if isinstance(p, re.Pattern):
+                if p.fullmatch(name):
+                    return True
+            elif isinstance(p, str) and p.startswith("re:"):
+                if re.fullmatch(p[3:], name):
+                    return True
+            elif p == name:
+                return True
+        return False
 
     sd = dict(state_dict)
     out = {}

@@ -216,17 +216,19 @@ class ColumnShardedQLinear(nn.Module):
 
     layout="rows" (default): the local GEMM writes y[:, n0:n1] shards; the all-gather lands them stacked and one layout pass
     builds row-major y[M, N].  layout="transposed" (SURVEY.md §8(e) option 1): the local GEMM writes the TRANSPOSED shard
-    yt[n0:n1, :] (pq_qlinear_s8_t, same bits), whose all-gather is contiguous — no staging buffer, no layout kernel; forward
-    returns yt.t(): a [.., M, N] view with strides (1, M) that holds exactly the values of the row-major result (a consumer that
-    needs row-major memory pays the transpose itself; one that indexes logically does not).
+    yt[n0:n1, :] (pq_qlinear_s8_t, same bits), whose all-gather is contiguous — no staging buffer, no layout kernel.  forward_t()
+    hands out yt[N, M] itself (for a consumer that is fed transposed or indexes logically); forward() stays a drop-in for
+    nn.Linear and returns ROW-MAJOR memory (one transpose copy: stock consumers such as `self.q_proj(h).view(...)` raise on a
+    strided view) unless the module was built with transposed_view=True, in which case it returns yt.t(), strides (1, M).
     overlap_chunks > 1 (layout="rows"): the rows are cut into blocks and each block's exchange overlaps the next block's GEMM —
     natively on the communicator's side stream (native_gather) or through torch.distributed's async collectives."""
 
     def __init__(self, local: qlinear, out_features: int, group=None, native_gather: "RcclColumnGather | None" = None,
-                 overlap_chunks: int = 1, layout: str = "rows"):
+                 overlap_chunks: int = 1, layout: str = "rows", transposed_view: bool = False):
         super().__init__()
         if layout not in ("rows", "transposed"):
             raise ValueError("layout must be 'rows' or 'transposed'")
+        self.transposed_view = transposed_view      # layout="transposed" only: forward() may return the strided view yt.t()
         self.local, self.out_features, self.group = local, out_features, group
         self.in_features = local.in_features
         self.native_gather = native_gather          # optional: exchange through libpq_rccl.so instead of torch.distributed
@@ -235,7 +237,9 @@ class ColumnShardedQLinear(nn.Module):
 
     @classmethod
     def from_linear(cls, lin: nn.Linear, group=None, native_gather=None, overlap_chunks: int = 1, layout: str = "rows",
-                    world=None, rank=None) -> "ColumnShardedQLinear":
+                    world=None, rank=None, transposed_view: bool = False) -> "ColumnShardedQLinear":
+        if (world is None) != (rank is None):
+            raise ValueError("ColumnShardedQLinear.from_linear: pass world and rank together (or neither: the process group's)")
         if world is None:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
         lo, hi = shard_bounds(lin.out_features, world, rank)
@@ -244,7 +248,7 @@ class ColumnShardedQLinear(nn.Module):
             sub.weight.copy_(lin.weight[lo:hi])
             if lin.bias is not None:
                 sub.bias.copy_(lin.bias[lo:hi])
-        return cls(qlinear.from_linear(sub), lin.out_features, group, native_gather, overlap_chunks, layout)
+        return cls(qlinear.from_linear(sub), lin.out_features, group, native_gather, overlap_chunks, layout, transposed_view)
 
     # the three device steps, separate so that host logic can be tested with them stubbed (tests/test_dist_gloo.py)
     def _quantize(self, x):
@@ -256,16 +260,24 @@ class ColumnShardedQLinear(nn.Module):
     def _local_t(self, codes, scales, dtype):
         return qlinear_s8_t(codes, scales, self.local.wq, self.local.ws, self.local.bias, dtype)
 
+    def forward_t(self, x: torch.Tensor) -> torch.Tensor:
+        """The transposed result yt[N, M] (M = all leading dimensions of x flattened), contiguous: the local GEMM writes transposed
+        shards and the gather lands them in place.  Any layout setting; no layout pass, no copy."""
+        xq = self._quantize(x)
+        codes = xq.int_data.reshape(-1, self.in_features)
+        yt_local = self._local_t(codes, xq.scale, x.dtype)
+        return self.native_gather.gather_t(yt_local, self.out_features) if self.native_gather is not None else \
+            gather_rows_t(yt_local, self.out_features, self.group)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.layout == "transposed":
+            y = self.forward_t(x).t()                                # [M, N] view, strides (1, M)
+            if not self.transposed_view:
+                y = y.contiguous()
+            return y if x.dim() == 2 else y.unflatten(0, x.shape[:-1])
         xq = self._quantize(x)
         codes = xq.int_data.reshape(-1, self.in_features)
         M = codes.shape[0]
-        if self.layout == "transposed":
-            yt_local = self._local_t(codes, xq.scale, x.dtype)
-            yt = self.native_gather.gather_t(yt_local, self.out_features) if self.native_gather is not None else \
-                gather_rows_t(yt_local, self.out_features, self.group)
-            y = yt.t()                                               # [M, N] view, strides (1, M)
-            return y if x.dim() == 2 else y.unflatten(0, x.shape[:-1])
         if self.overlap_chunks > 1 and self.native_gather is not None:
             lo, hi = shard_bounds(self.out_features, self.native_gather.world, self.native_gather.rank)
             y_local = torch.empty((M, hi - lo), dtype=x.dtype, device=x.device)
@@ -374,6 +386,8 @@ class RowShardedQLinear(nn.Module):
     @classmethod
     def from_linear(cls, lin: nn.Linear, group=None, scatter: bool = True, native=None, world=None, rank=None) -> "RowShardedQLinear":
         """world/rank default to the process group's; passing them builds a given rank's shard offline."""
+        if (world is None) != (rank is None):
+            raise ValueError("RowShardedQLinear.from_linear: pass world and rank together (or neither: the process group's)")
         if world is None:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
         return cls(cls.shard_of(lin, world, rank), lin.in_features, group, scatter, native)
@@ -407,6 +421,8 @@ class ShardedGatedMLP(nn.Module):
     @classmethod
     def from_linears(cls, gate: nn.Linear, up: nn.Linear, down: nn.Linear, group=None, scatter: bool = True, native=None,
                      world=None, rank=None):
+        if (world is None) != (rank is None):
+            raise ValueError("ShardedGatedMLP.from_linears: pass world and rank together (or neither: the process group's)")
         if world is None:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
         lo, hi = shard_bounds(gate.out_features, world, rank)

@@ -193,10 +193,16 @@ def _module_worker(rank, world, port, N, M, K, layout, chunks, q):
         m = Stub.__new__(Stub)
         torch.nn.Module.__init__(m)
         m.local, m.out_features, m.group, m.in_features, m.native_gather, m.overlap_chunks, m.layout = local, N, None, K, None, chunks, layout
+        m.transposed_view = False
         y = m(bf(x))
         ok = tuple(y.shape) == (M, N) and torch.equal(y.contiguous().view(torch.int16), bf(y_want).view(torch.int16))
         if layout == "transposed":
-            ok = ok and y.stride() == (1, M)            # a view of the contiguous y^T: no layout pass happened
+            ok = ok and y.is_contiguous()               # drop-in: stock consumers .view() the result
+            yt = m.forward_t(bf(x))                     # the contiguous y^T itself: no layout pass, no copy
+            ok = ok and tuple(yt.shape) == (N, M) and yt.is_contiguous() and torch.equal(yt.t().contiguous().view(torch.int16), bf(y_want).view(torch.int16))
+            m.transposed_view = True
+            ok = ok and m(bf(x)).stride() == (1, M)     # opt-in: a view of y^T
+            m.transposed_view = False
         y3 = m(bf(x).reshape(2, M // 2, K))             # [..., K] inputs
         ok = ok and tuple(y3.shape) == (2, M // 2, N) and torch.equal(y3.reshape(M, N).contiguous().view(torch.int16), bf(y_want).view(torch.int16))
         q.put((rank, bool(ok)))

@@ -52,4 +52,16 @@ def test_fused_llama_layers_match_unfused_and_oracle(pq):
     same(h.int_data, hq, "norm codes"); same(h.scale, hs, "norm scales")
     for out, n in ((q, "q_proj"), (k, "k_proj"), (v, "v_proj")):
         same(out.contiguous(), C.qlinear_s8(hq, hs, *C.quant_rowwise(bits(wts[n]), 0), None, 0), "fused " + n)
-    assert attn.qkv_fused._outs is None          # the shared result is released after its third consumer
+    assert attn.qkv_fused._outs is None          # nothing shared outlives the attention forward (slices called directly compute their own)
+    # a projection called twice on the same input (recompute, a hook), only SOME siblings called, an input changed in place
+    # between two forwards: none of them may serve a stale or mismatched result
+    with torch.no_grad():
+        q2 = attn.q_proj(h); q3 = attn.q_proj(h)                                   # twice, siblings never called
+        assert torch.equal(q2, q) and torch.equal(q3, q) and attn.qkv_fused._outs is None
+        b1 = model(ids).logits
+        model.model.embed_tokens.weight.mul_(2.0)                                  # same ids object, different hidden states
+        b2, a2 = model(ids).logits, None
+        unfused.model.embed_tokens.weight.mul_(2.0)
+        a2 = unfused(ids).logits
+    assert torch.equal(b1.view(torch.int16), b.view(torch.int16)) and torch.equal(a2.view(torch.int16), b2.view(torch.int16))
+    assert all(l.self_attn.qkv_fused._outs is None and l.self_attn.qkv_fused._key is None for l in model.model.layers)

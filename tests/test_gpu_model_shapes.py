@@ -93,6 +93,8 @@ def test_llama8b_prefill_shapes(pq, N, K, variant, bias):
     (1024, 28672, "ring128", False),          # down shard (column-sharded: full K)
     (16032, 8192, "sp256_16x16x64", False),   # lm_head shard: 128256 / 8 = 16032 = 62.6 tile columns (ragged last tile)
     (128, 8192, "", False),                   # k / v shard (8 KV heads x 128 / 8 GPUs)
+    (1280, 8192, "sp128x256", True),          # FUSED q+k+v shard, what bench.py --workload llama70b-shard runs: (8192 + 2 x 1024) / 8
+    (7168, 8192, "sp256_16x16x64", False),    # FUSED gate+up shard: 2 x 28672 / 8 (28 tile columns x 16 = 448 tiles: 1.75 rounds)
 ])
 def test_llama70b_shard_shapes(pq, N, K, variant, bias, pq_opt):
     y, acc = _check(pq, 4096, N, K, variant, bias=bias)
@@ -116,3 +118,42 @@ def test_70b_shard_splitk_forced_on_matches(pq, pq_opt):
     pq_opt("PQ_NO_SPLITK", "1")
     y2, _ = _check(pq, M, N, K, "")
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+
+
+@pytest.mark.parametrize("H,Kfull,name", [(8192, 8192, "o"), (8192, 28672, "down")])
+def test_llama70b_row_sharded_real_shapes(pq, H, Kfull, name):
+    """BASELINE configs[4], the row-sharded pairing of bench.py --workload llama70b-shard: `o` as 4096 x 8192 x 1024 and
+    `down` as 4096 x 8192 x 3584 per rank.  Two of the eight ranks are built offline on one GPU (RowShardedQLinear.from_linear with
+    world = 8), each computes its f32 partial from its own K-slice of the activation; partial(rank 0) + partial(rank 1), in f32, must
+    equal the oracle's restatement (full-row weight scales, per-slice activation scales, bias on rank 0) on 64 sampled token rows."""
+    from protoquant_amd.sharded import shard_bounds
+    M, world = 4096, 8
+    g = torch.Generator().manual_seed(70 + Kfull)
+    lin = torch.nn.Linear(Kfull, H, bias=True, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(H, Kfull, generator=g) * 0.02).to(torch.bfloat16))
+        lin.bias.copy_((torch.randn(H, generator=g) * 0.05).to(torch.bfloat16))
+    lin_g = torch.nn.Linear(Kfull, H, bias=True, dtype=torch.bfloat16, device="cuda")
+    lin_g.load_state_dict(lin.state_dict())
+    wq, ws = C.quant_rowwise(bits(lin.weight), 0)
+    rows = np.sort(np.random.default_rng(Kfull).choice(M, 64, replace=False))
+    total, want = None, None
+    for r in range(2):
+        k0, k1 = shard_bounds(Kfull, world, r)
+        assert k1 - k0 == Kfull // world
+        x = torch.randn(M, k1 - k0, generator=g).to(torch.bfloat16)          # this rank's local activation slice
+        layer = pq.RowShardedQLinear.from_linear(lin_g, world=world, rank=r)
+        same(layer.local.wq, np.ascontiguousarray(wq[:, k0:k1]), f"{name}: weight codes of rank {r}")
+        same(layer.local.ws, ws, f"{name}: full-row weight scales")
+        p = layer.partial(x.cuda())
+        assert p.dtype == torch.float32 and p.shape == (M, H)
+        total = p if total is None else total + p
+        xq, xs = C.quant_rowwise(np.ascontiguousarray(bits(x)[rows]), 0)
+        b = lin.bias.detach().float().numpy() if r == 0 else None
+        pw = C.qlinear_s8(xq, xs, np.ascontiguousarray(wq[:, k0:k1]), ws, b, 2)
+        same(p[torch.from_numpy(rows).cuda()].contiguous(), pw, f"{name}: f32 partial of rank {r}")
+        want = pw if want is None else (want + pw).astype(np.float32)
+    torch.cuda.synchronize()
+    same(total[torch.from_numpy(rows).cuda()].contiguous(), want, f"{name}: sum of two ranks' partials")
+    name_v = __import__("protoquant_amd")._lib.lib().pq_gemm_variant_name(M, H, Kfull // world, Kfull // world, Kfull // world).decode()
+    assert "sp256" in name_v, name_v

@@ -73,7 +73,7 @@ def test_convert_load_matches_swap_and_oracle(pq, tmp_path):
     torch.manual_seed(11)
     ref = Tiny().to(torch.bfloat16)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
-    conv = S.convert_checkpoint(sd, gated_mlp=[r"layers\.\d+\.mlp"])
+    conv = S.convert_checkpoint(sd, gated_mlp=[r"re:layers\.\d+\.mlp"])
     # every linear's codes and scales == the C oracle's quantisation of the checkpoint weight
     for k, w in sd.items():
         if k.endswith("o_proj.weight") or k.endswith("lm_head.weight") or k.endswith("q_proj.weight"):

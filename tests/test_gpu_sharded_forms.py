@@ -143,5 +143,39 @@ def test_workspace_is_bounded(pq):
     sizes = set()
     for M in range(1, 600, 7):
         lin(torch.randn(M, 512, device="cuda", dtype=torch.bfloat16))
-        sizes.add(next(iter(QL._WORKSPACES.values())).numel())
+        sizes.add(next(iter(QL._WORKSPACES.values()))[0].numel())
     assert len(QL._RETIRED) == 0 and len(QL._WORKSPACES) == 1 and len(sizes) <= 12
+
+
+def test_workspace_used_by_a_graph_survives_eager_growth(pq):
+    """a workspace allocated EAGERLY (the warm-up) and then used inside a hipGraph captured on the same stream is pinned by
+    that graph: a later eager call that outgrows it must park it, not free it — otherwise the caching allocator hands the block to other
+    tensors and a replay writes its scratch (here: the one-call path's codes and scales) into foreign memory.
+    Sequence: warm up, capture on the same stream, grow eagerly, allocate over the freed space, replay, compare bits."""
+    import sys
+    QL = sys.modules["protoquant_amd.qlinear"]
+    pq.clear_workspaces()
+    torch.manual_seed(3)
+    lin = pq.qlinear.from_linear(torch.nn.Linear(512, 256, bias=False, device="cuda", dtype=torch.bfloat16))
+    x = torch.randn(64, 512, device="cuda", dtype=torch.bfloat16)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        y_ref = lin(x).clone()                      # eager warm-up on stream s: allocates the workspace (not capturing)
+        g = torch.cuda.CUDAGraph()
+        out = torch.empty_like(y_ref)
+        with torch.cuda.graph(g, stream=s):         # the capture re-uses that buffer without growing it
+            out.copy_(lin(x))
+        ent = QL._WORKSPACES[("cuda", x.device.index, s.cuda_stream)]
+        assert ent[1], "a buffer handed out under capture must be marked graph-pinned"
+        old_ptr = ent[0].data_ptr()
+        lin(torch.randn(4096, 512, device="cuda", dtype=torch.bfloat16))      # eager, larger M: outgrows the pinned buffer
+        assert any(b.data_ptr() == old_ptr for b in QL._RETIRED), "the outgrown graph-pinned buffer was dropped"
+        junk = [torch.full((ent[0].numel(),), 0x5A, dtype=torch.uint8, device="cuda") for _ in range(8)]   # would land on a freed block
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), y_ref.view(torch.int16))
+        assert all(bool((j == 0x5A).all()) for j in junk), "the replay wrote into memory it no longer owned"
+    torch.cuda.current_stream().wait_stream(s)
+    pq.clear_workspaces()

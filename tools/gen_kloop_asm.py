@@ -1,0 +1,388 @@
+"""Generator of the hand-allocated K-loop of gemm_s8_sp256<..., P3> (protoquant_amd/csrc/kloop_p3_asm.inc).
+
+K-tiles 1 .. NT-1 of the split-ring 256 x 256 tile are emitted as ONE inline-asm statement per variant:
+  * a loop over one full ring turn (six K-tiles: lcm of the 3-slot weight ring and the 2-slot activation ring), so that every LDS
+    address is an immediate, for the tiles that issue both DMA sides (tiles 1 .. NT-4);
+  * behind each of the six places the loop can be left, the three closing tiles as straight-line code in that ring phase
+    (tile NT-3: activation pieces of tile NT-1 and the scale vectors, no weight pieces; tile NT-2: no DMA, drains vmcnt; tile NT-1:
+    nothing but MFMAs and its own fragment reads).
+The accumulators (128 VGPRs), both fragment sets (96) and the address registers are operands: hipcc allocates them once and nothing
+inside the statement can spill.  Per K-tile and wave in the loop: 64 v_mfma_i32_16x16x64_i8, 24 ds_read_b128, 8
+global_load_lds_dwordx4, one counted s_waitcnt + s_barrier, four counted lgkmcnt waits, ~10 SALU.
+
+The tile body follows the HIP lambda `tile` of gemm_s8_fast.hip operation for operation (same fragments into the same variables,
+same DMA pieces in the same per-wave issue order, the same vmcnt counts), so the statement is entered after the HIP code's tile 0
+(first-half prologue) and its results are the HIP loop's bit for bit.
+
+usage: python tools/gen_kloop_asm.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "protoquant_amd", "csrc", "kloop_p3_asm.inc")
+
+KB = 1024
+P_SLOT, Q_SLOT, HALF = 32 * KB, 32 * KB, 16 * KB
+QBASE = 3 * P_SLOT          # P ring: 3 slots of 32 KiB, then the Q ring: 2 slots of 32 KiB
+GP, GQ = "s[88:89]", "s[90:91]"     # pinned SGPR pairs: weight K cursor, activation K cursor (the statement advances them)
+
+
+class Emitter:
+    """Instruction list with byte offsets (8-byte alignment of 8-byte encodings) and an in-order model of the LDS-read queue."""
+
+    def __init__(self, align8, nowait, nobar):
+        self.lines = []
+        self.off = 0            # bytes since the statement's .p2align 3
+        self.align8 = align8
+        self.nowait = nowait
+        self.nobar = nobar
+        self.fifo = []          # outstanding ds_read destinations, oldest first
+        self.count = {}
+        self.m0_age = 9
+        self.uid = 0
+
+    def raw(self, text, size, klass):
+        if size == 8 and self.align8 and self.off % 8 == 4:
+            self.raw("s_nop 0", 4, "s_nop")
+        self.lines.append(text)
+        self.m0_age += 1
+        self.off += size
+        self.count[klass] = self.count.get(klass, 0) + 1
+
+    def label(self, name):
+        self.lines.append(name + ":")
+
+    def pad8(self):
+        if self.off % 8:
+            self.raw("s_nop 0", 4, "s_nop")
+
+    # ---- instructions
+    def mfma(self, d, a, b):
+        self.need([a, b])
+        self.raw(f"v_mfma_i32_16x16x64_i8 %[{d}], %[{a}], %[{b}], %[{d}]", 8, "mfma")
+
+    def ds_read(self, dst, base, imm):
+        assert 0 <= imm < 65536, imm
+        self.raw(f"ds_read_b128 %[{dst}], %[{base}]" + (f" offset:{imm}" if imm else ""), 8, "ds_read")
+        self.fifo.append(dst)
+
+    def need(self, regs):
+        """counted wait: everything up to the youngest outstanding read among `regs` must have returned (LDS returns in order)"""
+        last = -1
+        for i, r in enumerate(self.fifo):
+            if r in regs:
+                last = i
+        if last >= 0:
+            n = len(self.fifo) - 1 - last
+            self.fifo = self.fifo[last + 1:]
+            if not self.nowait:
+                self.raw(f"s_waitcnt lgkmcnt({n})", 4, "s_waitcnt")
+
+    def dma_m0(self, lds_lit, base="sbw"):
+        # M0 = LDS byte address of the piece (wave-uniform).  The DMA follows at least one instruction later (hazard: one wait state
+        # between an SALU write of M0 and the LDS-DMA that reads it); no other M0 write may come in between.
+        assert lds_lit >= 0
+        size = 4 if lds_lit <= 64 else 8
+        self.raw(f"s_add_u32 m0, %[{base}], 0x{lds_lit:x}", size, "salu")
+        self.m0_age = 0
+
+    def dma_load(self, voff, sbase):
+        if self.m0_age == 0:
+            self.raw("s_nop 0", 4, "s_nop")
+        self.raw(f"global_load_lds_dwordx4 %[{voff}], {sbase}", 8, "lds_dma")
+
+    def salu(self, text, size=4):
+        self.raw(text, size, "salu")
+
+    def branch(self, text):
+        self.raw(text, 4, "branch")
+
+    def barrier(self, vm):
+        if not self.nowait:
+            self.raw(f"s_waitcnt vmcnt({vm}) lgkmcnt(0)", 4, "s_waitcnt")
+        self.fifo = []
+        if not self.nobar:
+            self.raw("s_barrier", 4, "s_barrier")
+
+    def add64(self, pair, delta):
+        lo, hi = pair[2:-1].split(":")
+        if delta > 0:
+            self.salu(f"s_add_u32 s{lo}, s{lo}, 0x{delta:x}", 4 if delta <= 64 else 8)
+            self.salu(f"s_addc_u32 s{hi}, s{hi}, 0")
+        elif delta < 0:
+            self.salu(f"s_sub_u32 s{lo}, s{lo}, 0x{-delta:x}", 4 if -delta <= 64 else 8)
+            self.salu(f"s_subb_u32 s{hi}, s{hi}, 0")
+
+
+def acc(a, b, i, j):
+    return f"c{a}{b}{i}{j}"
+
+
+STEADY = [f"pa{it % 4}{it // 4}" for it in range(8)] + [f"qa{it % 2}{it // 2}" for it in range(4)]
+
+
+def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full"):
+    """One K-tile whose P data sits in P slot ps and Q data in Q slot qs.
+    flavour: "full" (a tile kt+3 exists: both DMA sides), "q" (tile NT-3: the Q side of tile NT-1 and the scale vectors), "none"
+    (tile NT-2: no DMA, every DMA piece must have landed at its barrier), "last" (tile NT-1: no next tile at all).
+    dma_slots: MFMA index (0..63) -> list of DMA piece ids g (0..3: Q side of tile kt+2 into Q slot qs, 4..7: P side of tile kt+3
+    into P slot ps), every id once, increasing over the tile, all behind the barrier (index >= 32).
+    ptr "imm" (loop tiles only): the K advance inside the turn rides in the instruction's immediate offset, (t - 5) * 128 <= 0, on
+    cursors biased by +640: measured on gfx950 (tools/ubench/glds_offset), the immediate moves the LDS destination as well as the
+    global source, so M0 carries the opposite bias (>= 0 this way)."""
+    psn, qsn = (ps + 1) % 3, (qs + 1) % 2
+    nxt_tile = flavour != "last"
+
+    def p_addr(slot, h, i, ks):          # (base operand, immediate) of P fragment i, k-step ks, half h of P slot `slot`
+        if slot == 2:
+            return f"bph{ks}", h * HALF + i * 2048
+        return f"bp{ks}", slot * P_SLOT + h * HALF + i * 2048
+
+    def q_addr(slot, h, j, ks):
+        return f"bq{ks}", slot * Q_SLOT + h * HALF + j * 2048
+
+    fill = {}                             # MFMA index -> list of callables
+
+    def add(idx, fn):
+        fill.setdefault(idx, []).append(fn)
+
+    rs = rstride                          # fragment reads in every rs-th MFMA shadow of their quadrant
+    for it in range(4):                   # q0 shadows: Q1[kt] -> fQb
+        j, ks = it % 2, it // 2
+        add(it * rs, lambda j=j, ks=ks: E.ds_read(f"qb{j}{ks}", *q_addr(qs, 1, j, ks)))
+    for it in range(8):                   # q1 shadows: P1[kt] -> fPb
+        i, ks = it % 4, it // 4
+        add(16 + it * rs, lambda i=i, ks=ks: E.ds_read(f"pb{i}{ks}", *p_addr(ps, 1, i, ks)))
+    if nxt_tile:
+        for it in range(8):               # q2 shadows: P0[kt+1] -> fPa
+            i, ks = it % 4, it // 4
+            add(32 + it * rs, lambda i=i, ks=ks: E.ds_read(f"pa{i}{ks}", *p_addr(psn, 0, i, ks)))
+        for it in range(4):               # q3 shadows: Q0[kt+1] -> fQa
+            j, ks = it % 2, it // 2
+            add(48 + it * rs, lambda j=j, ks=ks: E.ds_read(f"qa{j}{ks}", *q_addr(qsn, 0, j, ks)))
+
+    goff = (t - 5) * 128 if (ptr == "imm" and flavour == "full") else 0
+    osfx = f" offset:{goff}" if goff else ""
+    if flavour in ("full", "q"):
+        seen = []
+        for idx in sorted(dma_slots):
+            assert idx >= 32
+            for g in dma_slots[idx]:
+                if flavour == "q" and g >= 4:
+                    continue
+                seen.append(g)
+                # the M0 write in the shadow of MFMA idx, the DMA in the shadow of MFMA idx+1 (in front of the next piece's M0 write)
+                nxt = min(idx + 1, 63)
+                if g < 4:
+                    h, jj = g // 2, g % 2
+                    add(idx, lambda h=h, jj=jj: E.dma_m0(QBASE + qs * Q_SLOT + h * HALF + jj * KB - goff))
+                    add(nxt, lambda h=h, jj=jj: E.dma_load(f"oq{h}{jj}", GQ + osfx))
+                    if g == 3 and (ptr == "bump" or flavour == "q"):
+                        add(nxt, lambda: E.add64(GQ, 128))
+                    if g == 3 and flavour == "q":
+                        # tile NT-3: the two scale vectors (1 KiB each: waves 0 and 1 of the workgroup, 4 floats per lane) follow the Q
+                        # pieces into the P slot this tile has just vacated: no later DMA targets it, tile NT-2's vmcnt(0) covers them
+                        def scales():
+                            E.salu("s_cmp_eq_u32 %[dosc], 0")
+                            E.branch(f"s_cbranch_scc1 L_nosc{E.uid}_%=")
+                            E.dma_m0(ps * P_SLOT, base="sbs")
+                            E.raw("s_nop 0", 4, "s_nop")
+                            E.raw("global_load_lds_dwordx4 %[scsrc], off", 8, "lds_dma")
+                            E.label(f"L_nosc{E.uid}_%=")
+                            E.uid += 1
+                        add(min(nxt + 2, 63), scales)
+                else:
+                    h, jj = (g - 4) // 2, (g - 4) % 2
+                    add(idx, lambda h=h, jj=jj: E.dma_m0(ps * P_SLOT + h * HALF + jj * KB - goff))
+                    add(nxt, lambda h=h, jj=jj: E.dma_load(f"op{h}{jj}", GP + osfx))
+                    if g == 7 and ptr == "bump":
+                        add(nxt, lambda: E.add64(GP, 128))
+        assert seen == list(range(8 if flavour == "full" else 4)), seen
+
+    quads = [((0, 0), "pa", "qa"), ((0, 1), "pa", "qb"), ((1, 0), "pb", "qa"), ((1, 1), "pb", "qb")]
+    for q, ((a, b), fp, fq) in enumerate(quads):
+        if q == 2 and nxt_tile:
+            # tile kt+1 has landed and tile kt's slots are free.  full / q: the 4 P pieces of tile kt+2 may stay in flight
+            E.barrier(4 if flavour in ("full", "q") else 0)
+        for x in range(16):
+            ks, i, j = x // 8, (x // 2) % 4, x % 2
+            if x % 2 == 0:               # one counted wait for the fragments of this MFMA and the next
+                E.need([f"{fp}{i}{ks}", f"{fq}{j}{ks}", f"{fq}{j + 1}{ks}"])
+            E.mfma(acc(a, b, i, j), f"{fp}{i}{ks}", f"{fq}{j}{ks}")
+            for fn in fill.get(q * 16 + x, []):
+                fn()
+
+
+DMA_PLANS = {
+    # the HIP kernel's placement: eight consecutive shadows behind the eight fragment reads of quadrant 2
+    "hip": {40 + g: [g] for g in range(8)},
+    # one piece every second or third MFMA from the middle of quadrant 2 to the end of the tile
+    "spread": {40: [0], 43: [1], 46: [2], 52: [3], 55: [4], 57: [5], 59: [6], 61: [7]},
+    # quadrant 3 (behind its four fragment reads): what waves 4-7 use in the staggered forms
+    "late": {52 + g: [g] for g in range(8)},
+    # one piece every fourth MFMA over quadrants 2 and 3
+    "even4": {33 + 4 * g: [g] for g in range(8)},
+}
+
+
+# variant id -> dict(dma: plan of waves 0-3, dma_b: plan of waves 4-7 (None = same code), align8, nowait, nobar,
+#                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
+#                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
+def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0):
+    return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio)
+
+
+VARIANTS = {
+    1: V("spread"),                                # the product
+    2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
+    3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
+}
+
+
+def gen_loop(E, tag, plan, cfg):
+    """six tiles = one ring turn starting at K-tile index 1 (P slot 1, Q slot 1); leave after any tile when the count runs out"""
+    E.fifo = list(STEADY)
+    E.label(f"L_turn_{tag}_%=")
+    for t in range(6):
+        kt = 1 + t
+        gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"])
+        assert E.fifo == STEADY, (E.fifo, STEADY)
+        E.salu("s_sub_u32 %[cnt], %[cnt], 1")
+        E.branch(f"s_cbranch_scc1 L_exit{t}_%=")
+    if cfg["ptr"] == "imm":          # both K cursors advance by one turn (6 x 128 bytes)
+        E.add64(GQ, 768)
+        E.add64(GP, 768)
+    E.branch(f"s_branch L_turn_{tag}_%=")
+
+
+def gen_variant(vid):
+    cfg = VARIANTS[vid]
+    E = Emitter(cfg["align8"], cfg["nowait"], cfg["nobar"])
+    E.lines.append(".p2align 3")
+    E.raw("s_waitcnt lgkmcnt(0)", 4, "s_waitcnt")      # the fragment reads of tile 1 issued by the HIP code
+    E.salu("s_sub_u32 %[cnt], %[cnt], 1")              # cnt = number of full tiles (NT - 4 >= 1): zero-based countdown
+    if cfg["ptr"] == "imm":                            # bias of the K cursors (see gen_tile)
+        E.add64(GQ, 640)
+        E.add64(GP, 640)
+    two = cfg["dma_b"] is not None or cfg["prio"]
+    if two:
+        E.salu("s_cmp_eq_u32 %[half], 0")
+        E.branch("s_cbranch_scc0 L_half_b_%=")
+    E.pad8()
+    pre = dict(E.count)
+    gen_loop(E, "a", cfg["dma"], cfg)
+    per_tile = {k: (v - pre.get(k, 0)) / 6.0 for k, v in E.count.items() if (v - pre.get(k, 0))}
+    if two:
+        E.pad8()
+        E.label("L_half_b_%=")
+        if cfg["prio"]:
+            E.salu("s_setprio 1")
+        E.pad8()
+        gen_loop(E, "b", cfg["dma_b"] or cfg["dma"], cfg)
+    # behind exit t (the loop left after tile t of a turn): the K cursors are put right (imm: bias and the tiles of the unfinished turn),
+    # then the three closing tiles in ring phase t+1
+    for t in range(6):
+        E.pad8()
+        E.label(f"L_exit{t}_%=")
+        if cfg["ptr"] == "imm":
+            E.add64(GQ, (t + 1) * 128 - 640)
+            E.add64(GP, (t + 1) * 128 - 640)
+        E.fifo = list(STEADY)
+        for k, fl in enumerate(("q", "none", "last")):
+            kt = 1 + t + 1 + k
+            gen_tile(E, kt % 3, kt % 2, DMA_PLANS[cfg["dma"]], 0, "bump", cfg["rstride"], fl)
+        assert E.fifo == [], E.fifo
+        if t < 5:
+            E.branch("s_branch L_done_%=")
+    E.pad8()
+    E.label("L_done_%=")
+    if cfg["prio"]:
+        E.salu("s_setprio 0")
+    E.raw("s_nop 7", 4, "s_nop")                       # MFMA results -> any non-MFMA reader after the statement
+    E.raw("s_nop 7", 4, "s_nop")
+    return E, per_tile
+
+
+def c_operands():
+    outs, ins = [], []
+    for a in range(2):
+        for b in range(2):
+            for i in range(4):
+                for j in range(2):
+                    outs.append(f'[{acc(a, b, i, j)}] "+v"(acc[{a}][{b}][{i}][{j}])')
+    for name, var, n in (("pa", "fPa", 4), ("pb", "fPb", 4), ("qa", "fQa", 2), ("qb", "fQb", 2)):
+        for i in range(n):
+            for ks in range(2):
+                outs.append(f'[{name}{i}{ks}] "+v"({var}[{i}][{ks}])')
+    outs.append('"+{s[88:89]}"(gp64)')
+    outs.append('"+{s[90:91]}"(gq64)')
+    outs.append('[cnt] "+s"(cnt)')
+    for ks in range(2):
+        ins.append(f'[bp{ks}] "v"(bp[{ks}])')
+        ins.append(f'[bph{ks}] "v"(bph[{ks}])')
+        ins.append(f'[bq{ks}] "v"(bq[{ks}])')
+    for h in range(2):
+        for jj in range(2):
+            ins.append(f'[op{h}{jj}] "v"(offP[{h}][{jj}])')
+            ins.append(f'[oq{h}{jj}] "v"(offQ[{h}][{jj}])')
+    ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[half] "s"(half)']
+    return outs, ins
+
+
+def render():
+    out = []
+    out.append("// GENERATED by tools/gen_kloop_asm.py -- do not edit; `python tools/gen_kloop_asm.py` rewrites it, tests/test_asm_guards.py")
+    out.append("// checks that the committed file is what the generator produces.")
+    out.append("// kloop_p3_asm<V>: K-tiles 1 .. NT-1 of gemm_s8_sp256<..., P3 = true> (NT >= 5) as one hand-allocated asm statement:")
+    out.append("// nfull = NT - 4 tiles in a loop over ring turns, then the three closing tiles.  scale_src / sbs / do_scales: the per-lane source")
+    out.append("// address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector DMA, issued in tile NT-3.")
+    out.append("#pragma once")
+    out.append("namespace pq {")
+    out.append("template <int V> __device__ __forceinline__ void kloop_p3_asm(v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],")
+    out.append("        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],")
+    out.append("        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,")
+    out.append("        uint32_t sbw, uint32_t half, const void* scale_src, uint32_t sbs, uint32_t do_scales) {")
+    out.append("    uint64_t gp64 = reinterpret_cast<uint64_t>(gP), gq64 = reinterpret_cast<uint64_t>(gQ);")
+    out.append("    uint32_t cnt = nfull;")
+    outs, ins = c_operands()
+    first = True
+    mixes = {}
+    for vid in sorted(VARIANTS):
+        E, per_tile = gen_variant(vid)
+        mixes[vid] = per_tile
+        out.append(f"    {'if' if first else 'else if'} constexpr (V == {vid}) {{")
+        out.append(f"        // {VARIANTS[vid]}")
+        out.append("        // loop, per K-tile and wave: " + ", ".join(f"{k} {v:g}" for k, v in sorted(per_tile.items())))
+        out.append("        asm volatile(")
+        for l in E.lines:
+            out.append('            "' + l + '\\n\\t"')
+        out.append("            : " + ",\n              ".join(outs))
+        out.append("            : " + ",\n              ".join(ins))
+        out.append('            : "memory", "scc");')
+        out.append("    }")
+        first = False
+    out.append("    else static_assert(V < 0, \"unknown K-loop variant\");")
+    out.append("    gP = reinterpret_cast<const int8_t*>(gp64);")
+    out.append("    gQ = reinterpret_cast<const int8_t*>(gq64);")
+    out.append("}")
+    out.append("}  // namespace pq")
+    return "\n".join(out) + "\n", mixes
+
+
+def main():
+    text, mixes = render()
+    if "--check" in sys.argv:
+        cur = open(OUT).read() if os.path.exists(OUT) else ""
+        if cur != text:
+            print("kloop_p3_asm.inc is stale: run python tools/gen_kloop_asm.py")
+            sys.exit(1)
+        return
+    with open(OUT, "w") as f:
+        f.write(text)
+    for vid, m in mixes.items():
+        print(f"variant {vid} {VARIANTS[vid]}: loop, per K-tile per wave: " + ", ".join(f"{k} {v:g}" for k, v in sorted(m.items())))
+
+
+if __name__ == "__main__":
+    main()
