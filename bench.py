@@ -272,7 +272,7 @@ def run_mlp(args):
                        "what": f"{len(layers)} blocks with distinct weights ({len(layers) * 135} MB) run one after the other: every block streams its weights from HBM"}
         except Exception as e:      # an extra figure must never lose the main line
             print(f"[bench] HBM-fed leg failed: {e}", file=sys.stderr)
-    print(json.dumps({"metric": "int8 TOPS, Llama MLP block (gate/up/down as qlinear)", "value": round(ops * args.steps / dt / 1e12, 2),
+    emit_json({"metric": "int8 TOPS, Llama MLP block (gate/up/down as qlinear)", "value": round(ops * args.steps / dt / 1e12, 2),
                       "unit": "TOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": "Llama MLP block 4096->11008->4096, seq 2048, gate+up fused (BASELINE configs[2])",
@@ -283,7 +283,7 @@ def run_mlp(args):
                       "roofline": {"bound": "mfma", "achieved": round(ops * args.steps / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops * args.steps / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
                                    "note": "whole block incl. both activation quantisations (the second fused with silu*mul), not a single kernel"},
-                      "cpu_baseline": None}), flush=True)
+                      "cpu_baseline": None})
 
 
 def run_llama8b_linears(args):
@@ -343,7 +343,7 @@ def run_llama8b_linears(args):
     ops = L * (2.0 * M * 6144 * H + 2.0 * M * H * H + 2.0 * M * 2 * I * H + 2.0 * M * H * I) + 2.0 * M * V * H
     wbytes = L * (6144 * H + H * H + 2 * I * H + H * I) + V * H          # int8 weight bytes streamed per pass
     if M <= 512:       # decode-like: the pass is a streaming read of the weights — report it against HBM, not MFMA
-        print(json.dumps({"metric": f"weight-streaming TB/s, Llama-3-8B linears at {M} tokens (decode-like)", "value": round(wbytes / dt / 1e12, 3),
+        emit_json({"metric": f"weight-streaming TB/s, Llama-3-8B linears at {M} tokens (decode-like)", "value": round(wbytes / dt / 1e12, 3),
                           "unit": "TB/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                           "config": {"workload": f"Llama-3-8B every linear as qlinear (qkv and gate/up fused) at {M} tokens, linears + quant passes only",
@@ -352,9 +352,9 @@ def run_llama8b_linears(args):
                           "roofline": {"bound": "hbm", "achieved": round(wbytes / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": round(wbytes / dt / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                                        "note": "whole pass (290 kernels); algorithmic bytes = the int8 weights only"},
-                          "cpu_baseline": None}), flush=True)
+                          "cpu_baseline": None})
         return
-    print(json.dumps({"metric": "int8 TOPS, Llama-3-8B linears at prefill seq 4096", "value": round(ops / dt / 1e12, 2), "unit": "TOPS",
+    emit_json({"metric": "int8 TOPS, Llama-3-8B linears at prefill seq 4096", "value": round(ops / dt / 1e12, 2), "unit": "TOPS",
                       "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": "Llama-3-8B every linear as qlinear (qkv and gate/up fused), bs 1 seq 4096, linears + quant passes only (BASELINE configs[3])",
@@ -363,7 +363,7 @@ def run_llama8b_linears(args):
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
                                    "note": "whole pass incl. every activation quantisation (silu*mul fused into down's) and the strided read of the qkv slice"},
-                      "cpu_baseline": None}), flush=True)
+                      "cpu_baseline": None})
 
 
 def run_llama8b(args):
@@ -445,7 +445,7 @@ def run_llama8b(args):
     t_lin = lin_t[len(lin_t) // 2]
     L, H, I, V = cfg.num_hidden_layers, 4096, 14336, cfg.vocab_size
     ops = L * (2.0 * S * 6144 * H + 2.0 * S * H * H + 2.0 * S * 2 * I * H + 2.0 * S * H * I) + 2.0 * S * V * H
-    print(json.dumps({"metric": "int8 TOPS of the linear path + end-to-end prefill latency, Llama-3-8B (every nn.Linear as qlinear), bs 1 seq 4096",
+    emit_json({"metric": "int8 TOPS of the linear path + end-to-end prefill latency, Llama-3-8B (every nn.Linear as qlinear), bs 1 seq 4096",
                       "value": round(ops / t_lin / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(lat), "warmup": 2, "ms_per_step": round(e2e * 1e3, 3),
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": f"transformers LlamaForCausalLM at Llama-3-8B dims ({L} layers), synthetic weights, swap_linears(fuse_gated_mlp) + fuse_llama_layers, prefill bs 1 seq {S} (BASELINE configs[3])",
@@ -456,7 +456,7 @@ def run_llama8b(args):
                       "roofline": {"bound": "mfma", "achieved": round(ops / t_lin / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / t_lin / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
                                    "note": "all int8-path launches of the forward: fused RMSNorm+quant (x2 per layer), fused qkv, o, fused gate+up, silu*mul+quant, down, lm_head (its own K1); HIP events around those modules"},
-                      "cpu_baseline": None}), flush=True)
+                      "cpu_baseline": None})
 
 
 def run_llama70b_shard(args):
@@ -541,7 +541,7 @@ def run_llama70b_shard(args):
     # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
     gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
     t_gather = gathered * (G - 1) / G / (7 * 153e9)
-    print(json.dumps({"metric": "int8 TOPS per GPU, Llama-3-70B column-sharded over 8 GPUs: one rank's linears at M=4096 (exchange modelled)",
+    emit_json({"metric": "int8 TOPS per GPU, Llama-3-70B column-sharded over 8 GPUs: one rank's linears at M=4096 (exchange modelled)",
                       "value": round(ops / dt / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(ts), "warmup": 2, "ms_per_step": round(dt * 1e3, 3),
                       "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
                       "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
@@ -552,11 +552,34 @@ def run_llama70b_shard(args):
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
                                    "note": "one rank's compute only: every activation quantisation (RMSNorm fused for q/k/v and gate/up) + the shard GEMMs"},
-                      "cpu_baseline": None}), flush=True)
+                      "cpu_baseline": None})
+
+
+_JSON_FD = None
+
+
+def _claim_stdout():
+    """The driver reads ONE JSON line from stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when
+    a communicator is created, flushed at exit): from here on file descriptor 1 goes to stderr, and the JSON line alone is written to
+    the original stdout (emit_json)."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
 
 
 def main():
     args = parse()
+    _claim_stdout()
     if args.workload == "llama8b":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"
         return run_llama8b(args) if args.tokens > 512 else run_llama8b_linears(args)
@@ -972,7 +995,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
             const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok && w < 2));   // ("s" operands must be provably uniform)
             kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
-                               (uint32_t)(wave >> 2), ssrc, smem_base + (uint32_t)w * 1024u, do_scales);
+                               0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales);
         }
     } else {
     while (kt + DEPTH < NT) { tile(kt, slot, qslot, yes, yes, yes); adv(); }
@@ -603,6 +603,233 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_s8_p3_persist — the split-ring 256 x 256 tile for grids of MORE than one round (gate+up: 7 rounds, lm_head: 31): one
+// workgroup per CU walks its output tiles (ids b, b + G, b + 2G, ...: the same XCD every time), so that what a fresh workgroup
+// pays per round — launch, address set-up, the DMA issue burst and the first-touch latency of its first K-tile (weights come from
+// HBM inside a model: 2.6 us of the 47 us a round takes, measured with the in-kernel stamps) — overlaps the previous tile's epilogue:
+//   * behind the last K-tile of tile i (one barrier: every wave has read its last fragments) the first K-tile of tile i+1 is DMA'd
+//     into the ring slots the last K-tile has just vacated — the epilogue stages through the slots of K-tile NT-2 and keeps the
+//     scales in K-tile NT-3's weight slot, so all three P slots and both Q slots are spoken for and nothing collides;
+//   * the epilogue of tile i runs (its 16 - 32 stores per wave are issued behind those 8 DMA pieces: a counted vmcnt leaves exactly
+//     the stores in flight), one barrier, then K-tiles 1 and 2 are requested and the asm statement runs ALL K-tiles of tile i+1,
+//     entered at the ring phase the previous tile left (kloop_p3_asm: `phase`).
+// Every output tile is computed by the same instruction sequence as in gemm_s8_sp256<..., P3, ASMV = 1> apart from its first K-tile
+// (here a regular tile of the statement instead of the HIP code's first-half form): integer sums, same epilogue -> same bits.
+template <int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_s8_p3_persist(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W, int64_t ldw,
+                                                             EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int PHB = 128 * FBK, QHB = 128 * FBK, PB = 2 * PHB, QB = 2 * QHB, QBASE = 3 * PB;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[3 * PB + 2 * QB];
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wp = w >> 2, wq = w & 3;
+    const int NT = K / FBK;                                  // >= 4 (launcher)
+    const int ntiles = tiles_m * tiles_n;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t sbw = smem_base + (uint32_t)w * 2048u, sbs = smem_base + (uint32_t)w * 1024u;
+    constexpr int WM = 64, WN = 128;
+    // Register budget: 128 accumulators + 96 fragment registers + the statement's 15 address registers leave ~15 VGPRs.  Everything that
+    // depends on the lane is therefore recomputed where it is used, from a copy of the lane id that the compiler cannot see through —
+    // hoisted out of the tile loop, those values stay live across the statement AND the epilogue and spill.
+    auto lane_now = [&]() { int l = (int)threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; };
+
+    struct Src { uint32_t offP[2][2], offQ[2][2]; const int8_t *gP, *gQ; int m0, n0; };
+    // coordinates of output tile `tix` and the per-lane source offsets of this wave's DMA pieces (as in gemm_s8_sp256)
+    auto locate = [&](int tix, Src& o) {
+        const int lane = lane_now();
+        const int t = xcd_remap(tix, ntiles);
+        constexpr int GM = 4;
+        const int band = t / (GM * tiles_n);
+        const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
+        const int tin = t - band * GM * tiles_n;
+        o.m0 = (band * GM + tin % gm) * 256; o.n0 = (tin / gm) * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int piece = w * 2 + jj, r = piece * 8 + (lane >> 3);
+                const int src_chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+                int nl = (r / 64) * 128 + h * 64 + (r % 64);
+                nl = (o.n0 + nl < N) ? nl : (N - 1 - o.n0);
+                o.offP[h][jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
+                int ml = (r / 32) * 64 + h * 32 + (r % 32);
+                ml = (o.m0 + ml < M) ? ml : (M - 1 - o.m0);
+                o.offQ[h][jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
+            }
+        o.gP = W + (int64_t)o.n0 * ldw; o.gQ = X + (int64_t)o.m0 * ldx;
+    };
+    // one K-tile side of this wave: 4 pieces into ring slot `slot`, from the tile's first K byte + koff
+    auto dma_p = [&](const Src& o, int slot, int koff) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) glds16_sbase(o.gP + koff, o.offP[h][jj], sbw + slot * PB + h * PHB + jj * 1024);
+    };
+    auto dma_q = [&](const Src& o, int slot, int koff) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) glds16_sbase(o.gQ + koff, o.offQ[h][jj], sbw + QBASE + slot * QB + h * QHB + jj * 1024);
+    };
+    auto inc3 = [](int v, int d) { return (v + d) % 3; };
+
+    using acc_t = v4i;
+    acc_t acc[2][2][4][2];
+    int sp = 0, sq = 0;                                      // ring slots of the current output tile's K-tile 0
+    int tix = (int)blockIdx.x;
+    {
+        Src s0;
+        locate(tix, s0);
+        dma_p(s0, 0, 0); dma_q(s0, 0, 0);                    // first tile: its K-tile 0, waited for in full (once per workgroup)
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+    }
+    for (;;) {
+        int cm0, cn0;
+        {
+            // K-tile 0 sits in (sp, sq), visible to all.  Request K-tile 1 (weights first: the statement's issue order) and the weights of K-tile 2.
+            Src cur;
+            locate(tix, cur);
+            cm0 = cur.m0; cn0 = cur.n0;
+            dma_p(cur, inc3(sp, 1), FBK); dma_q(cur, sq ^ 1, FBK); dma_p(cur, inc3(sp, 2), 2 * FBK);
+            const int8_t* cP = cur.gP + 3 * FBK;             // the statement's cursors: weights of K-tile 3, activations of K-tile 2
+            const int8_t* cQ = cur.gQ + 2 * FBK;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) { acc[a][b][i][j] = v4i{0, 0, 0, 0}; asm volatile("" : "+v"(acc[a][b][i][j])); }
+            const int lane = lane_now();
+            const int frow = lane & 15, fchunk = lane >> 4, fkey = (frow >> 1) & 7;
+            uint32_t bp[2], bph[2], bq[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ks * 4 + fchunk;
+                bp[ks] = smem_base + (uint32_t)((wp * 64 + frow) * 128 + ((c ^ fkey) * 16));
+                bph[ks] = bp[ks] + 2 * PB;
+                bq[ks] = smem_base + QBASE + (uint32_t)((wq * 32 + frow) * 128 + ((c ^ fkey) * 16));
+            }
+            v4i fPa[4][2], fPb[4][2], fQa[2][2], fQb[2][2];
+            {
+                const uint32_t po = (uint32_t)(sp * PB), qo = (uint32_t)(sq * QB);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) fPa[it % 4][it / 4] = *reinterpret_cast<const v4i*>(smem + (bp[it / 4] - smem_base) + po + (it % 4) * 2048);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) fQa[it % 2][it / 2] = *reinterpret_cast<const v4i*>(smem + (bq[it / 2] - smem_base) + qo + (it % 2) * 2048);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) fPb[it % 4][it / 4] = v4i{0, 0, 0, 0};      // (written by the statement before it reads them)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) fQb[it % 2][it / 2] = v4i{0, 0, 0, 0};
+            }
+            // position of K-tile 0 in the statement's turn: position p holds (P slot (p + 1) % 3, Q slot (p + 1) % 2)  [CRT: p + 1 = 4 sp + 3 sq mod 6]
+            const int phase = __builtin_amdgcn_readfirstlane((4 * sp + 3 * sq + 5) % 6);
+            const bool scales_ok_ = (OUT == OUT_I32) ||
+                ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
+            const int sbase = w == 0 ? cm0 : cn0, slim = w == 0 ? M : N;
+            int e0 = sbase + lane * 4;
+            e0 = e0 + 3 < slim ? e0 : (slim >= 4 ? slim - 4 : 0);
+            const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
+            const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok_ && w < 2));
+            cP -= phase * FBK; cQ -= phase * FBK;            // immediate-offset form: position `phase` of the first turn addresses this tile
+            kloop_p3_asm<1>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, cur.offP, cur.offQ, cP, cQ, (uint32_t)(NT - 3), sbw, (uint32_t)phase, ssrc, sbs, do_scales);
+        }
+        // ---- behind the last K-tile: its slots take the next output tile's first K-tile
+        const int spl = inc3(sp, (NT - 1) % 3), sql = (sq + NT - 1) & 1;      // slots of K-tile NT-1
+        const int nxt = tix + (int)gridDim.x;
+        const bool more = nxt < ntiles;
+        if (more) {
+            __builtin_amdgcn_s_barrier();                    // every wave has read its last fragments
+            Src nx;
+            locate(nxt, nx);
+            dma_p(nx, spl, 0); dma_q(nx, sql, 0);
+        }
+        // ---- K4 epilogue of the tile just finished (as in gemm_s8_sp256; ring slots relative to this tile's phase)
+        using O = typename OutElem<OUT>::type;
+        constexpr int OB = (int)sizeof(O);
+        O* y = reinterpret_cast<O*>(epi.y);
+        const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
+        const bool scales_ok = (OUT == OUT_I32) ||
+            ((((reinterpret_cast<uintptr_t>(epi.a_scale) | reinterpret_cast<uintptr_t>(epi.b_scale)) & 15) == 0) && M >= 4 && N >= 4);
+        const int lane = lane_now();
+        const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
+        const int wm0 = cm0 + wq * WM, wn0 = cn0 + wp * WN;
+        const int scale_off = inc3(sp, NT % 3) * PB;                                    // K-tile NT-3's weight slot
+        const bool staged = scales_ok && (wm0 + WM <= M) && (wn0 + WN <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+                            (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
+        constexpr int NSTORE = (OB == 2) ? 16 : 32;          // global stores per wave of the staged epilogue
+        if (staged) {
+            constexpr int WREG = 8192;
+            const uint32_t sw_off = (uint32_t)((w < 4 ? inc3(sp, (NT + 1) % 3) * PB : QBASE + ((sq + NT) & 1) * QB) + (w & 3) * WREG);   // K-tile NT-2's slots
+            constexpr int NPT = 8, NQT = 4;
+            constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;
+            constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
+            constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
+            static_assert((NQT / QT_PASS) * (NPT / PT_PASS) * (QT_PASS * 16 / (64 / (PT_PASS * 16 * OB / 16))) == NSTORE, "store count of the staged epilogue");
+            auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt / 4][qt / 2][pt % 4][qt % 2]; };
+            auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + qt * 16 + dcol]; };
+            auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + scale_off + 1024 + (wp * WN + pt * 16 + drow4) * 4); };
+            uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0);
+            const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0)) : nullptr;
+            PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane);
+        } else {
+            const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
+#pragma unroll
+            for (int hQ = 0; hQ < 2; ++hQ)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = wm0 + hQ * 32 + j * 16 + dcol;
+                    const bool mok = m < M;
+                    float as = 1.0f;
+                    if constexpr (OUT != OUT_I32) as = mok ? epi.a_scale[m] : 0.0f;
+#pragma unroll
+                    for (int hP = 0; hP < 2; ++hP)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int n = wn0 + hP * 64 + i * 16 + drow4;
+                            if (!mok || n >= N) continue;
+                            const acc_t& c = acc[hP][hQ][i][j];
+                            O* dst = y + (int64_t)m * epi.ldy + n;
+                            O o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int nn = n + r < N ? n + r : N - 1;
+                                float bs = 1.0f, bf = 0.0f;
+                                if constexpr (OUT != OUT_I32) {
+                                    bs = epi.b_scale[nn];
+                                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : nn);
+                                }
+                                o[r] = epi_convert<OUT>(c[r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
+                            }
+                            if (n + 3 < N && vec_ok) {
+                                if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+                                else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = o[r];
+                            }
+                        }
+                }
+        }
+        if (!more) break;
+        // the next tile's first K-tile must have landed: its 8 pieces are OLDER than this epilogue's stores (vmcnt retires in order), so
+        // the staged path leaves exactly its stores in flight; the direct path (edge tiles, compiler-counted stores and loads) drains
+        if (staged) __builtin_amdgcn_s_waitcnt(waitcnt_imm(NSTORE, 0));
+        else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();                        // visible to all; the staging slots and the scale slot are free again
+        tix = nxt; sp = spl; sq = sql;
+    }
+}
+
+template <int OUT>
+void launch_gemm_p3_persist(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    const int nt = tiles_m * tiles_n;
+    gemm_s8_p3_persist<OUT><<<dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+}
+
 bool gemm_fast_eligible(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return M >= 1 && N >= 1 && K >= FBK && (K % FBK) == 0 && (lda % 16) == 0 && (ldb % 16) == 0 && al(A) && al(B) &&
@@ -615,6 +842,11 @@ int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(
 
 bool g_sp128_lc = true;     // loader / consumer split of the 128 x 256 tile (pq_set_option("PQ_SP128_LC", "0") restores the 8-wave form)
 void set_sp128_lc(bool v) { g_sp128_lc = v; }
+// multi-round grids of the 256 x 256 tile through gemm_s8_p3_persist: OFF by default — bit-identical, race-screened, and measured 0 .. 1.7 % SLOWER than one workgroup
+// per tile (profiles/r03_ab_persistent.txt: the hardware dispatcher already overlaps a finished workgroup's store drain with its successor's prologue and
+// balances the tiles dynamically; the persistent form can prefetch only ONE K-tile under the epilogue — the rings are full — and then waits for the second)
+bool g_sp256_persist = false;
+void set_sp256_persist(bool v) { g_sp256_persist = v; }   // pq_set_option("PQ_SP256_PERSIST", "1")
 int g_sp256_asm = 1;        // K-loop variant of kloop_p3_asm.inc (pq_set_option("PQ_SP256_ASM", "n")); 0 = the HIP loop
 void set_sp256_asm(int v) { g_sp256_asm = v < 0 ? 1 : v; }
 bool g_sp256_p3 = true;     // split rings of the 256 x 256 tile: weights 3 slots deep (pq_set_option("PQ_SP256_P3", "0") restores the 2-deep ring)
@@ -662,6 +894,10 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
             // K-tiles 1 .. NT-1 in the hand-allocated asm statement (kloop_p3_asm.inc, variant 1) whenever there are at least five K-tiles;
             // PQ_SP256_ASM=0 keeps the HIP loop (same bits), 2 / 3 are the A/B and timing-only variants (bf16 output only)
             const int av = K >= 5 * FBK ? g_sp256_asm : 0;
+            if (av == 1 && g_sp256_persist && tiles_m * tiles_n > 256) {       // more than one round: one workgroup per CU walks its tiles
+                launch_gemm_p3_persist<OUT>(A, lda, B, ldb, epi, M, N, K, st);
+                return;
+            }
             if (av == 1) {
                 gemm_s8_sp256<OUT, 0, TM, TN, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
                 return;

@@ -1,0 +1,75 @@
+"""Child process of tests/test_gpu_multirank.py: ONE rank of a multi-GPU job (one process per GPU, RANK / WORLD_SIZE / MASTER_* from the
+environment, gloo for the bootstrap, libpq_rccl.so for the data path).  Every rank holds the full weights, so each result is checked
+locally against the unsharded qlinear — bit for bit for the gathers, and for the reduce-scatter at two ranks (a two-term f32 sum has
+one order).  Prints 'OK <rank>' on success; any assertion kills the job (the parent checks every rank's output)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import protoquant_amd as pq
+    from protoquant_amd.sharded import shard_bounds
+    gather = pq.RcclColumnGather()
+    assert gather.comm_ranks() == world
+    bits = lambda t: t.contiguous().view(torch.int16)          # noqa: E731
+    for (M, N, K, bias) in ((700, 384, 256, True), (513, 391, 384, False), (4096, 4096, 1024, False)):     # equal, ragged, full-size shards
+        torch.manual_seed(7 + N)                                                                           # same weights on every rank
+        lin = torch.nn.Linear(K, N, bias=bias, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        for kw in ({}, {"overlap_chunks": 3}, {"layout": "transposed"}, {"layout": "transposed", "transposed_view": True}):
+            m = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather, **kw)
+            y1 = m(x)
+            torch.cuda.synchronize()
+            assert tuple(y1.shape) == (M, N) and torch.equal(bits(y0), bits(y1)), (rank, M, N, K, kw)
+        yt = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather, layout="transposed").forward_t(x)
+        assert yt.is_contiguous() and torch.equal(bits(yt.t()), bits(y0))
+        # the whole sharded step replayed from a hipGraph: GEMM + RCCL exchange captured (what bench.py --gpus N times)
+        m = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather)
+        m(x); torch.cuda.synchronize()
+        out = torch.empty_like(y0)
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out.copy_(m(x))
+            for _ in range(3):
+                out.zero_(); g.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(bits(out), bits(y0)), (rank, "graph replay", M, N, K)
+        # row-sharded pairing: K split over the ranks, f32 partials, native reduce-scatter of row blocks (equal blocks only)
+        if M % world:
+            continue
+        rs = pq.RcclRowReduceScatter(gather)
+        lay = pq.RowShardedQLinear.from_linear(lin, native=rs)
+        k0, k1 = shard_bounds(K, world, rank)
+        yr = lay(x[:, k0:k1].contiguous())
+        total = None
+        for r in range(world):                       # every rank's partial rebuilt locally, summed in rank order
+            a, b = shard_bounds(K, world, r)
+            p = pq.RowShardedQLinear.from_linear(lin, world=world, rank=r).partial(x[:, a:b].contiguous())
+            total = p if total is None else total + p
+        m0, m1 = shard_bounds(M, world, rank)
+        torch.cuda.synchronize()
+        if world == 2:
+            assert torch.equal(bits(yr), bits(total[m0:m1].to(torch.bfloat16))), (rank, "reduce-scatter", M, N, K)
+        else:
+            assert torch.allclose(yr.float(), total[m0:m1], rtol=2e-2, atol=1e-3)
+    dist.barrier()
+    gather.close()
+    dist.destroy_process_group()
+    print(f"OK {rank}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,7 @@ def test_split_ring_gemm_does_not_spill(code_objects):
     seen = 0
     for _, meta in code_objects:
         for blk in re.split(r"\n\s+- \.agpr_count", meta):
-            m = re.search(r"\.name:\s+(\S*gemm_s8_sp256\S*)", blk)
+            m = re.search(r"\.name:\s+(\S*gemm_s8_(?:sp256|p3_persist)\S*)", blk)
             if not m:
                 continue
             seen += 1

@@ -157,3 +157,32 @@ def test_llama70b_row_sharded_real_shapes(pq, H, Kfull, name):
     same(total[torch.from_numpy(rows).cuda()].contiguous(), want, f"{name}: sum of two ranks' partials")
     name_v = __import__("protoquant_amd")._lib.lib().pq_gemm_variant_name(M, H, Kfull // world, Kfull // world, Kfull // world).decode()
     assert "sp256" in name_v, name_v
+
+
+def test_persistent_multi_round_kernel_matches(pq, pq_opt):
+    """gemm_s8_p3_persist (opt-in, PQ_SP256_PERSIST=1: one workgroup per CU walks its tiles, the next tile's first K-tile prefetched under
+    the epilogue, the asm K-loop entered at the ring phase the previous tile left) against the default one-workgroup-per-tile launch: a
+    7-round grid, a ragged one (edge tiles through the direct epilogue) with a bias, and the shortest K the form accepts — bit for bit,
+    and the default itself against the oracle on sampled rows."""
+    from protoquant_amd import _lib
+    for (M, N, K, bias) in ((4096, 28672, 4096, False), (4000, 9000, 1024, True), (4352, 4608, 640, False)):
+        y0, acc0 = _check(pq, M, N, K, "sp256", bias=bias, nrows=16) if M == 4096 else (None, None)
+        q = None
+        g = torch.Generator(device="cuda").manual_seed(N + K)
+        xq = (torch.randn(M, K, device="cuda", generator=g) * 28).round().clamp(-127, 127).to(torch.int8)
+        wq = (torch.randn(N, K, device="cuda", generator=g) * 28).round().clamp(-127, 127).to(torch.int8)
+        xs = torch.rand(M, device="cuda", generator=g) * 1e-2 + 1e-4
+        ws = torch.rand(N, device="cuda", generator=g) * 1e-2 + 1e-4
+        b = (torch.randn(N, device="cuda", generator=g) * 0.05).to(torch.bfloat16) if bias else None
+        ya = pq.qlinear_s8(xq, xs, wq, ws, b, torch.bfloat16)
+        fa = pq.qlinear_s8(xq, xs, wq, ws, b.float() if bias else None, torch.float32)
+        pq_opt("PQ_SP256_PERSIST", "1")
+        yb = pq.qlinear_s8(xq, xs, wq, ws, b, torch.bfloat16)
+        fb = pq.qlinear_s8(xq, xs, wq, ws, b.float() if bias else None, torch.float32)
+        ib = pq.int_mm(xq, wq)
+        pq_opt("PQ_SP256_PERSIST", "0")
+        ia = pq.int_mm(xq, wq)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int16), yb.view(torch.int16)), (M, N, K, "bf16")
+        assert torch.equal(fa.view(torch.int32), fb.view(torch.int32)), (M, N, K, "f32")
+        assert torch.equal(ia, ib), (M, N, K, "int32")

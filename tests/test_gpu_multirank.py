@@ -1,0 +1,109 @@
+"""-m gpu: the native exchange (libpq_rccl.so) over REAL ranks — one child process per GPU — when the box has at least two GPUs
+(skipped on a 1-GPU box: there the same code runs at world 1, below), plus the graph-captured forms at world 1:
+the whole tp step of bench.py (K1 + shard GEMM + RCCL all-gather + layout pass in one hipGraph) and the row-chunked exchange on the
+communicator's side stream (pq_allgather_cols_rows_async / pq_comm_join) under stream capture."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pq():
+    import protoquant_amd
+    from protoquant_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return protoquant_amd
+
+
+def _spawn(world, port):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o))
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_exchange_over_real_ranks(world):
+    """RcclColumnGather (equal and ragged shards; whole, row-chunked overlapped, transposed; graph-captured) and RcclRowReduceScatter
+    across `world` processes, one per GPU, each result compared with the unsharded qlinear on its own rank."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    outs = _spawn(world, 29570 + world)
+    for r, (rc, o) in enumerate(outs):
+        assert rc == 0 and f"OK {r}" in o, f"rank {r} failed (rc {rc}):\n{o[-3000:]}"
+
+
+def test_overlapped_exchange_under_graph_capture_world1(pq):
+    """pq_allgather_cols_rows_async + pq_comm_join captured into a hipGraph (the side stream forks from and joins the capturing
+    stream through the communicator's events): three row blocks per forward, replayed, bit-identical to the plain qlinear."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        gather = pq.RcclColumnGather()
+        torch.manual_seed(9)
+        lin = torch.nn.Linear(512, 640, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(900, 512, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        m = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather, overlap_chunks=3)
+        m(x); torch.cuda.synchronize()                       # allocates the exchange workspace outside the capture
+        out = torch.empty_like(y0)
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out.copy_(m(x))
+            for _ in range(4):
+                out.zero_()
+                g.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), y0.view(torch.int16))
+        y1 = m(x)                                            # the eager form still works after a capture used the same events
+        torch.cuda.synchronize()
+        assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
+        gather.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_bench_tp_step_is_one_graph_world1():
+    """bench.py --mode tp on ONE GPU (a 1-rank RCCL communicator): the step the driver times at N > 1 — K1, the shard GEMM, the RCCL
+    all-gather and the layout pass — is replayed whole from a hipGraph, and the line carries compute and exchange separately."""
+    env = dict(os.environ, MASTER_PORT="29563", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3",
+                        "--warmup-seconds", "0.3", "--no-cpu-baseline", "--no-gpu-context", "--no-dp-leg"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])       # (RCCL prints its version banner to stdout as well)
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["collective_in_graph"] is True, line["config"]
+    assert line["config"]["rccl_ranks"] == 1 and "captured in the graph" in line["config"]["launch"]
+    assert line["host_bound"] is False and line["exchange_us"] > 0 and line["compute_us"] > 0
+    assert line["ms_per_step"] * 1e3 >= 0.9 * line["compute_us"]                 # the exchange is in the step
+    assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True

@@ -246,6 +246,9 @@ def gen_loop(E, tag, plan, cfg):
     E.label(f"L_turn_{tag}_%=")
     for t in range(6):
         kt = 1 + t
+        if t:
+            E.pad8()
+            E.label(f"L_tile{t}_{tag}_%=")          # entry points of the phase jump (a statement may start anywhere in the turn)
         gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"])
         assert E.fifo == STEADY, (E.fifo, STEADY)
         E.salu("s_sub_u32 %[cnt], %[cnt], 1")
@@ -266,9 +269,13 @@ def gen_variant(vid):
         E.add64(GQ, 640)
         E.add64(GP, 640)
     two = cfg["dma_b"] is not None or cfg["prio"]
-    if two:
-        E.salu("s_cmp_eq_u32 %[half], 0")
-        E.branch("s_cbranch_scc0 L_half_b_%=")
+    assert not two, "the phase jump below enters loop a only"
+    # ring phase of the first tile: position `phase` of the turn (0 = P slot 1 / Q slot 1, the tile behind the HIP code's tile 0; the
+    # persistent kernel starts an output tile wherever the previous one left the rings).  With immediate offsets the caller has moved the
+    # cursors back by phase * 128 bytes, so that position `phase` of the first turn addresses the first tile.
+    for t in range(1, 6):
+        E.salu(f"s_cmp_eq_u32 %[phase], {t}")
+        E.branch(f"s_cbranch_scc1 L_tile{t}_a_%=")
     E.pad8()
     pre = dict(E.count)
     gen_loop(E, "a", cfg["dma"], cfg)
@@ -326,7 +333,7 @@ def c_operands():
         for jj in range(2):
             ins.append(f'[op{h}{jj}] "v"(offP[{h}][{jj}])')
             ins.append(f'[oq{h}{jj}] "v"(offQ[{h}][{jj}])')
-    ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[half] "s"(half)']
+    ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[phase] "s"(phase)']
     return outs, ins
 
 
@@ -335,14 +342,16 @@ def render():
     out.append("// GENERATED by tools/gen_kloop_asm.py -- do not edit; `python tools/gen_kloop_asm.py` rewrites it, tests/test_asm_guards.py")
     out.append("// checks that the committed file is what the generator produces.")
     out.append("// kloop_p3_asm<V>: K-tiles 1 .. NT-1 of gemm_s8_sp256<..., P3 = true> (NT >= 5) as one hand-allocated asm statement:")
-    out.append("// nfull = NT - 4 tiles in a loop over ring turns, then the three closing tiles.  scale_src / sbs / do_scales: the per-lane source")
-    out.append("// address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector DMA, issued in tile NT-3.")
+    out.append("// nfull tiles that issue both DMA sides in a loop over ring turns, then the three closing tiles.  phase: position of the first tile")
+    out.append("// in the turn (0 behind the HIP code's tile 0; with immediate offsets the cursors come in moved back by phase * 128 bytes).")
+    out.append("// scale_src / sbs / do_scales: the per-lane source address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector")
+    out.append("// DMA, issued in the third tile from the end.")
     out.append("#pragma once")
     out.append("namespace pq {")
     out.append("template <int V> __device__ __forceinline__ void kloop_p3_asm(v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],")
     out.append("        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],")
     out.append("        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,")
-    out.append("        uint32_t sbw, uint32_t half, const void* scale_src, uint32_t sbs, uint32_t do_scales) {")
+    out.append("        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales) {")
     out.append("    uint64_t gp64 = reinterpret_cast<uint64_t>(gP), gq64 = reinterpret_cast<uint64_t>(gQ);")
     out.append("    uint32_t cnt = nfull;")
     outs, ins = c_operands()
