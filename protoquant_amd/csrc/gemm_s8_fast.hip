@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
             const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok && w < 2));   // ("s" operands must be provably uniform)
             kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
-                               0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales);
+                               0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
         }
     } else {
     while (kt + DEPTH < NT) { tile(kt, slot, qslot, yes, yes, yes); adv(); }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_p3_persist(const int8_t* __res
             const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
             const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok_ && w < 2));
             cP -= phase * FBK; cQ -= phase * FBK;            // immediate-offset form: position `phase` of the first turn addresses this tile
-            kloop_p3_asm<1>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, cur.offP, cur.offQ, cP, cQ, (uint32_t)(NT - 3), sbw, (uint32_t)phase, ssrc, sbs, do_scales);
+            kloop_p3_asm<1>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, cur.offP, cur.offQ, cP, cQ, (uint32_t)(NT - 3), sbw, (uint32_t)phase, ssrc, sbs, do_scales, (uint32_t)(w >> 2));
         }
         // ---- behind the last K-tile: its slots take the next output tile's first K-tile
         const int spl = inc3(sp, (NT - 1) % 3), sql = (sq + NT - 1) & 1;      // slots of K-tile NT-1

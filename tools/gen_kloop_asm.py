@@ -122,7 +122,7 @@ def acc(a, b, i, j):
 STEADY = [f"pa{it % 4}{it // 4}" for it in range(8)] + [f"qa{it % 2}{it // 2}" for it in range(4)]
 
 
-def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full"):
+def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", tailprio=-1):
     """One K-tile whose P data sits in P slot ps and Q data in Q slot qs.
     flavour: "full" (a tile kt+3 exists: both DMA sides), "q" (tile NT-3: the Q side of tile NT-1 and the scale vectors), "none"
     (tile NT-2: no DMA, every DMA piece must have landed at its barrier), "last" (tile NT-1: no next tile at all).
@@ -205,6 +205,15 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full"):
         if q == 2 and nxt_tile:
             # tile kt+1 has landed and tile kt's slots are free.  full / q: the 4 P pieces of tile kt+2 may stay in flight
             E.barrier(4 if flavour in ("full", "q") else 0)
+            if flavour == "none" and tailprio >= 0:
+                # Behind the LAST barrier of the tile the waves run free for 1.5 K-tiles.  One wave of every SIMD pair (w and w + 4 share a
+                # SIMD) takes the matrix pipe by priority: it finishes its MFMAs in about half the time and runs its epilogue — vector
+                # ALU, LDS, stores — beside the partner's MFMAs instead of beside the partner's epilogue.
+                E.salu(f"s_cmp_eq_u32 %[half], {tailprio}")
+                E.branch(f"s_cbranch_scc0 L_noprio{E.uid}_%=")
+                E.salu("s_setprio 1")
+                E.label(f"L_noprio{E.uid}_%=")
+                E.uid += 1
         for x in range(16):
             ks, i, j = x // 8, (x // 2) % 4, x % 2
             if x % 2 == 0:               # one counted wait for the fragments of this MFMA and the next
@@ -229,14 +238,16 @@ DMA_PLANS = {
 # variant id -> dict(dma: plan of waves 0-3, dma_b: plan of waves 4-7 (None = same code), align8, nowait, nobar,
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
-def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0):
-    return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio)
+def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1):
+    return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio)
 
 
 VARIANTS = {
     1: V("spread"),                                # the product
     2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
+    # (tailprio=0 / 1 — one wave of every SIMD pair takes the matrix pipe behind the last barrier so that its epilogue runs beside the partner's MFMAs — was
+    # built and measured: +-0.1 % on every shape, profiles/r03_ab_asm_kloop.txt run 4; the generator keeps the option, the library does not instantiate it)
 }
 
 
@@ -298,12 +309,14 @@ def gen_variant(vid):
         E.fifo = list(STEADY)
         for k, fl in enumerate(("q", "none", "last")):
             kt = 1 + t + 1 + k
-            gen_tile(E, kt % 3, kt % 2, DMA_PLANS[cfg["dma"]], 0, "bump", cfg["rstride"], fl)
+            gen_tile(E, kt % 3, kt % 2, DMA_PLANS[cfg["dma"]], 0, "bump", cfg["rstride"], fl, cfg["tailprio"])
         assert E.fifo == [], E.fifo
         if t < 5:
             E.branch("s_branch L_done_%=")
     E.pad8()
     E.label("L_done_%=")
+    # (a raised priority stays through the epilogue: the early wave's vector work wins the issue slots its partner's MFMAs leave; the HIP code
+    # after the statement never lowers it, the wave ends with its epilogue)
     if cfg["prio"]:
         E.salu("s_setprio 0")
     E.raw("s_nop 7", 4, "s_nop")                       # MFMA results -> any non-MFMA reader after the statement
@@ -333,7 +346,7 @@ def c_operands():
         for jj in range(2):
             ins.append(f'[op{h}{jj}] "v"(offP[{h}][{jj}])')
             ins.append(f'[oq{h}{jj}] "v"(offQ[{h}][{jj}])')
-    ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[phase] "s"(phase)']
+    ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[phase] "s"(phase)', '[half] "s"(half)']
     return outs, ins
 
 
@@ -351,7 +364,7 @@ def render():
     out.append("template <int V> __device__ __forceinline__ void kloop_p3_asm(v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],")
     out.append("        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],")
     out.append("        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,")
-    out.append("        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales) {")
+    out.append("        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales, uint32_t half) {")
     out.append("    uint64_t gp64 = reinterpret_cast<uint64_t>(gP), gq64 = reinterpret_cast<uint64_t>(gQ);")
     out.append("    uint32_t cnt = nfull;")
     outs, ins = c_operands()
