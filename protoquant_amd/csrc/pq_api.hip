@@ -25,6 +25,7 @@ template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
+void set_k1_st16(bool);
 void set_k1_lds(int);
 void set_ring_lc(bool);
 void set_sp128_lc(bool);
@@ -84,7 +85,7 @@ Options g_opt;
 std::once_flag g_opt_once;
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_SKINNY_RB"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
@@ -97,6 +98,7 @@ bool apply_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_SP256_PERSIST")) pq::set_sp256_persist(value && *value == '1');
     else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
+    else if (!strcmp(name, "PQ_K1_ST16")) pq::set_k1_st16(value && *value == '1');
     else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
     else return false;

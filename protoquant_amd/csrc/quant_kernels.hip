@@ -12,7 +12,9 @@ namespace pq {
 // reduction and the encode: ONE HBM read.  Algorithmic traffic: read once, write 1 B/elem + 4 B/row.
 // RPW (TPR = 64 only): rows per wave; 2 issues both rows' loads up front (an experiment that measured slower: see
 // launch_rowwise_vec).
-template <int DT, int VPT, int TPR, int RPW = 1>
+// ST16 (16-bit inputs, TPR = 64, even nvec, 16-byte aligned code rows): 16-byte stores — adjacent lanes swap halves (DPP quad_perm [1,0,3,2]) so that an
+// even lane holds the 16 consecutive codes of vector pair (idx, idx + 1) of segment i and its odd neighbour those of segment i + 1; loads stay dense.
+template <int DT, int VPT, int TPR, int RPW = 1, bool ST16 = false>
 __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restrict__ x, int64_t rows, int nvec,
                                                          int64_t ldx_bytes, int8_t* __restrict__ q, int64_t ldq,
                                                          float* __restrict__ scale) {
@@ -85,6 +87,23 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
         };
         if (!has_nan && scale_fast_ok(s)) {       // the hot path: no division per element, results identical to x / s
             const float r = 1.0f / s;
+            if constexpr (ST16 && EPV == 8 && TPR == kWave && (VPT % 2) == 0) {
+                const bool odd = t & 1;
+#pragma unroll
+                for (int i = 0; i < VPT; i += 2) {
+                    float fa[EPV], fb[EPV];
+                    Unpack<DT, EPV>::run(v[rr][i], fa);
+                    Unpack<DT, EPV>::run(v[rr][i + 1], fb);
+                    uint32_t a[2], b[2];
+                    fast_encode<EPV, kQuotientSteps<DT>>(fa, s, r, a);
+                    fast_encode<EPV, kQuotientSteps<DT>>(fb, s, r, b);
+                    const uint32_t na0 = __builtin_amdgcn_update_dpp(0u, a[0], 0xB1, 0xF, 0xF, false), na1 = __builtin_amdgcn_update_dpp(0u, a[1], 0xB1, 0xF, 0xF, false);
+                    const uint32_t nb0 = __builtin_amdgcn_update_dpp(0u, b[0], 0xB1, 0xF, 0xF, false), nb1 = __builtin_amdgcn_update_dpp(0u, b[1], 0xB1, 0xF, 0xF, false);
+                    const v4u o = odd ? v4u{nb0, nb1, b[0], b[1]} : v4u{a[0], a[1], na0, na1};
+                    const int first = odd ? (i + 1) * TPR + t - 1 : i * TPR + t;        // first vector of this lane's pair (even: nvec is even, so the pair is in or out as a whole)
+                    if (first < nvec) store_wt_b128(qr + (int64_t)first * 8, o);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 const int idx = i * TPR + t;
@@ -93,6 +112,7 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
                 uint32_t pk[EPV / 4];
                 fast_encode<EPV, kQuotientSteps<DT>>(f, s, r, pk);
                 if (idx < nvec) store_vec(idx, pk);
+            }
             }
         } else {                                  // uniform per row group: true division (NaN/Inf data, extreme scales)
 #pragma unroll 1
@@ -345,6 +365,8 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
 // host-side launchers (called from pq_api.hip)
 static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
+bool g_k1_st16 = false;   // 16-byte code stores in K1 (pq_set_option("PQ_K1_ST16", "1")): A/B in profiles/r03_k1_st16.txt
+void set_k1_st16(bool v) { g_k1_st16 = v; }
 int g_k1_rpw = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_K1_RPW"))
 void set_k1_rpw(int v) { g_k1_rpw = v; }
 int g_k1_lds = 0;     // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU (pq_set_option("PQ_K1_LDS"))
@@ -373,6 +395,15 @@ static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, i
         }
     }
     const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
+    if constexpr (TPR == kWave && Elem<DT>::kBytes == 2) {
+        if (g_k1_st16 && (nvec & 1) == 0 && (ldq & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 && vpt >= 2 && vpt <= 8) {
+            switch (vpt) {
+                case 2: quant_rowwise_vec<DT, 2, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 4: quant_rowwise_vec<DT, 4, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                default: quant_rowwise_vec<DT, 8, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+            }
+        }
+    }
     switch (vpt) {
         case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
         case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;

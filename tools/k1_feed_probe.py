@@ -35,7 +35,7 @@ def graph(fns, n):
             for f in fns: f()
     return g
 def setopts(cfg):
-    for k in ("PQ_K1_RPW", "PQ_K1_LDS"):
+    for k in ("PQ_K1_RPW", "PQ_K1_LDS", "PQ_K1_ST16"):
         LL.set_option(k, "0")
     if cfg != "-":
         for kv in cfg.split(","):
