@@ -868,7 +868,7 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         if (g_sp256_p3 && gemm_debug_flags() == 1024) {      // stamps only, around an asm K-loop variant
             switch (K >= 5 * FBK ? g_sp256_asm : 0) {
 #define PQ_ASMS(n) case n: gemm_s8_sp256<OUT, 1024, TM, TN, false, true, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1024, g_stamps, 1); return;
-                PQ_ASMS(1) PQ_ASMS(2)
+                PQ_ASMS(1) PQ_ASMS(2) PQ_ASMS(3) PQ_ASMS(6) PQ_ASMS(7) PQ_ASMS(8) PQ_ASMS(9)
 #undef PQ_ASMS
                 default: break;
             }
@@ -905,6 +905,12 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
             if constexpr (OUT == PQ_BF16) {
                 if (av == 2) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
                 if (av == 3) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 3><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+#ifdef PQ_ABLATION_BUILD      // timing-only ablations of the asm loop (dev builds)
+                if (av == 6) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 6><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+                if (av == 7) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 7><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+                if (av == 8) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 8><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+                if (av == 9) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 9><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
+#endif
             }
             gemm_s8_sp256<OUT, 0, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
             return;

@@ -71,17 +71,19 @@ class _SharedFused(nn.Module):
         return self.fused(x)[index]
 
 
-def _install_qkv_hooks(attn: nn.Module, shared: _SharedFused) -> None:
-    def pre(mod, args, kwargs):
-        x = kwargs.get("hidden_states", args[0] if args else None)
-        if x is not None:
-            shared.begin(x)
+def _qkv_pre_hook(mod, args, kwargs):
+    x = kwargs.get("hidden_states", args[0] if args else None)
+    if x is not None:
+        mod.qkv_fused.begin(x)          # (looked up on the module, not captured: a deep copy of the model shares nothing with its original)
 
-    def post(mod, args, kwargs, out):
-        shared.end()
 
-    attn.register_forward_pre_hook(pre, with_kwargs=True)
-    attn.register_forward_hook(post, with_kwargs=True, always_call=True)
+def _qkv_post_hook(mod, args, kwargs, out):
+    mod.qkv_fused.end()
+
+
+def _install_qkv_hooks(attn: nn.Module) -> None:
+    attn.register_forward_pre_hook(_qkv_pre_hook, with_kwargs=True)
+    attn.register_forward_hook(_qkv_post_hook, with_kwargs=True, always_call=True)
 
 
 def _is_rmsnorm(m) -> bool:
@@ -101,7 +103,7 @@ def fuse_llama_layers(model: nn.Module, fuse_norms: bool = True, fuse_qkv: bool 
         if fuse_qkv:
             attn.qkv_fused = _SharedFused(FusedQLinear([q, k, v]))
             attn.q_proj, attn.k_proj, attn.v_proj = (_FusedSlice(attn.qkv_fused, i) for i in range(3))
-            _install_qkv_hooks(attn, attn.qkv_fused)
+            _install_qkv_hooks(attn)
         if fuse_norms and _is_rmsnorm(layer.input_layernorm):
             layer.input_layernorm = RMSNormQuant(layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
         mlp_ok = isinstance(mlp, GatedMLP) or all(isinstance(getattr(mlp, p, None), qlinear) for p in ("gate_proj", "up_proj"))

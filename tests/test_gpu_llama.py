@@ -65,3 +65,11 @@ def test_fused_llama_layers_match_unfused_and_oracle(pq):
         a2 = unfused(ids).logits
     assert torch.equal(b1.view(torch.int16), b.view(torch.int16)) and torch.equal(a2.view(torch.int16), b2.view(torch.int16))
     assert all(l.self_attn.qkv_fused._outs is None and l.self_attn.qkv_fused._key is None for l in model.model.layers)
+    # a deep copy of the fused model shares nothing with the original: its attention hooks drive its own fused GEMM
+    clone = copy.deepcopy(model)
+    calls = []
+    clone.model.layers[0].self_attn.qkv_fused.fused.register_forward_hook(lambda *a: calls.append(1))
+    with torch.no_grad():
+        b3 = clone(ids).logits
+    assert torch.equal(b3.view(torch.int16), b2.view(torch.int16)) and len(calls) == 1      # ONE fused qkv GEMM per forward of that layer
+    assert all(l.self_attn.qkv_fused._outs is None for l in model.model.layers)

@@ -31,7 +31,8 @@ GP, GQ = "s[88:89]", "s[90:91]"     # pinned SGPR pairs: weight K cursor, activa
 class Emitter:
     """Instruction list with byte offsets (8-byte alignment of 8-byte encodings) and an in-order model of the LDS-read queue."""
 
-    def __init__(self, align8, nowait, nobar):
+    def __init__(self, align8, nowait, nobar, nodma=False, nolds=False):
+        self.nodma, self.nolds = nodma, nolds           # timing-only ablations: drop the LDS-DMA / the fragment reads
         self.lines = []
         self.off = 0            # bytes since the statement's .p2align 3
         self.align8 = align8
@@ -64,6 +65,9 @@ class Emitter:
 
     def ds_read(self, dst, base, imm):
         assert 0 <= imm < 65536, imm
+        if self.nolds:
+            self.fifo.append(dst)          # (keeps the queue model, and with it the counted waits, as in the real loop)
+            return
         self.raw(f"ds_read_b128 %[{dst}], %[{base}]" + (f" offset:{imm}" if imm else ""), 8, "ds_read")
         self.fifo.append(dst)
 
@@ -83,11 +87,15 @@ class Emitter:
         # M0 = LDS byte address of the piece (wave-uniform).  The DMA follows at least one instruction later (hazard: one wait state
         # between an SALU write of M0 and the LDS-DMA that reads it); no other M0 write may come in between.
         assert lds_lit >= 0
+        if self.nodma:
+            return
         size = 4 if lds_lit <= 64 else 8
         self.raw(f"s_add_u32 m0, %[{base}], 0x{lds_lit:x}", size, "salu")
         self.m0_age = 0
 
     def dma_load(self, voff, sbase):
+        if self.nodma:
+            return
         if self.m0_age == 0:
             self.raw("s_nop 0", 4, "s_nop")
         self.raw(f"global_load_lds_dwordx4 %[{voff}], {sbase}", 8, "lds_dma")
@@ -187,8 +195,9 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
                             E.salu("s_cmp_eq_u32 %[dosc], 0")
                             E.branch(f"s_cbranch_scc1 L_nosc{E.uid}_%=")
                             E.dma_m0(ps * P_SLOT, base="sbs")
-                            E.raw("s_nop 0", 4, "s_nop")
-                            E.raw("global_load_lds_dwordx4 %[scsrc], off", 8, "lds_dma")
+                            if not E.nodma:
+                                E.raw("s_nop 0", 4, "s_nop")
+                                E.raw("global_load_lds_dwordx4 %[scsrc], off", 8, "lds_dma")
                             E.label(f"L_nosc{E.uid}_%=")
                             E.uid += 1
                         add(min(nxt + 2, 63), scales)
@@ -238,14 +247,20 @@ DMA_PLANS = {
 # variant id -> dict(dma: plan of waves 0-3, dma_b: plan of waves 4-7 (None = same code), align8, nowait, nobar,
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
-def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1):
-    return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio)
+def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False):
+    return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio, nodma=nodma, nolds=nolds,
+                nowalk=nowalk)
 
 
 VARIANTS = {
     1: V("spread"),                                # the product
     2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
+    # timing only (wrong results), the ablations of round 2 on the asm loop: what the MFMA stream costs without its operand traffic
+    6: V("spread", nodma=True),                    # no LDS-DMA (the fragment reads return stale LDS bytes)
+    7: V("spread", nolds=True),                    # no fragment reads (the MFMAs run on whatever the registers hold)
+    8: V("spread", nodma=True, nolds=True),        # neither: the bare MFMA stream with the loop's waits and barriers
+    9: V("spread", nowalk=True),                   # the K cursors never leave the first ring turn: every DMA piece is an L2 hit (no fabric traffic), everything else as in 1
     # (tailprio=0 / 1 — one wave of every SIMD pair takes the matrix pipe behind the last barrier so that its epilogue runs beside the partner's MFMAs — was
     # built and measured: +-0.1 % on every shape, profiles/r03_ab_asm_kloop.txt run 4; the generator keeps the option, the library does not instantiate it)
 }
@@ -264,7 +279,7 @@ def gen_loop(E, tag, plan, cfg):
         assert E.fifo == STEADY, (E.fifo, STEADY)
         E.salu("s_sub_u32 %[cnt], %[cnt], 1")
         E.branch(f"s_cbranch_scc1 L_exit{t}_%=")
-    if cfg["ptr"] == "imm":          # both K cursors advance by one turn (6 x 128 bytes)
+    if cfg["ptr"] == "imm" and not cfg["nowalk"]:          # both K cursors advance by one turn (6 x 128 bytes)
         E.add64(GQ, 768)
         E.add64(GP, 768)
     E.branch(f"s_branch L_turn_{tag}_%=")
@@ -272,7 +287,7 @@ def gen_loop(E, tag, plan, cfg):
 
 def gen_variant(vid):
     cfg = VARIANTS[vid]
-    E = Emitter(cfg["align8"], cfg["nowait"], cfg["nobar"])
+    E = Emitter(cfg["align8"], cfg["nowait"], cfg["nobar"], cfg["nodma"], cfg["nolds"])
     E.lines.append(".p2align 3")
     E.raw("s_waitcnt lgkmcnt(0)", 4, "s_waitcnt")      # the fragment reads of tile 1 issued by the HIP code
     E.salu("s_sub_u32 %[cnt], %[cnt], 1")              # cnt = number of full tiles (NT - 4 >= 1): zero-based countdown
