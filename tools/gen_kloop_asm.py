@@ -130,7 +130,7 @@ def acc(a, b, i, j):
 STEADY = [f"pa{it % 4}{it // 4}" for it in range(8)] + [f"qa{it % 2}{it // 2}" for it in range(4)]
 
 
-def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", tailprio=-1):
+def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", tailprio=-1, snake=False):
     """One K-tile whose P data sits in P slot ps and Q data in Q slot qs.
     flavour: "full" (a tile kt+3 exists: both DMA sides), "q" (tile NT-3: the Q side of tile NT-1 and the scale vectors), "none"
     (tile NT-2: no DMA, every DMA piece must have landed at its barrier), "last" (tile NT-1: no next tile at all).
@@ -225,8 +225,10 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
                 E.uid += 1
         for x in range(16):
             ks, i, j = x // 8, (x // 2) % 4, x % 2
+            if snake and i % 2 == 1:     # boustrophedon: consecutive MFMAs always share one operand (P or Q fragment)
+                j = 1 - j
             if x % 2 == 0:               # one counted wait for the fragments of this MFMA and the next
-                E.need([f"{fp}{i}{ks}", f"{fq}{j}{ks}", f"{fq}{j + 1}{ks}"])
+                E.need([f"{fp}{i}{ks}", f"{fq}{0}{ks}", f"{fq}{1}{ks}"])
             E.mfma(acc(a, b, i, j), f"{fp}{i}{ks}", f"{fq}{j}{ks}")
             for fn in fill.get(q * 16 + x, []):
                 fn()
@@ -247,14 +249,15 @@ DMA_PLANS = {
 # variant id -> dict(dma: plan of waves 0-3, dma_b: plan of waves 4-7 (None = same code), align8, nowait, nobar,
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
-def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False):
+def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False, snake=False):
     return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio, nodma=nodma, nolds=nolds,
-                nowalk=nowalk)
+                nowalk=nowalk, snake=snake)
 
 
 VARIANTS = {
     1: V("spread"),                                # the product
     2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
+    # (snake=True — boustrophedon MFMA order inside a quadrant, so that consecutive MFMAs always share one operand — measured +-0.2 %: profiles/r03_ab_asm_kloop.txt run 5)
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
     # timing only (wrong results), the ablations of round 2 on the asm loop: what the MFMA stream costs without its operand traffic
     6: V("spread", nodma=True),                    # no LDS-DMA (the fragment reads return stale LDS bytes)
@@ -275,7 +278,7 @@ def gen_loop(E, tag, plan, cfg):
         if t:
             E.pad8()
             E.label(f"L_tile{t}_{tag}_%=")          # entry points of the phase jump (a statement may start anywhere in the turn)
-        gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"])
+        gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"], snake=cfg["snake"])
         assert E.fifo == STEADY, (E.fifo, STEADY)
         E.salu("s_sub_u32 %[cnt], %[cnt], 1")
         E.branch(f"s_cbranch_scc1 L_exit{t}_%=")
@@ -324,7 +327,7 @@ def gen_variant(vid):
         E.fifo = list(STEADY)
         for k, fl in enumerate(("q", "none", "last")):
             kt = 1 + t + 1 + k
-            gen_tile(E, kt % 3, kt % 2, DMA_PLANS[cfg["dma"]], 0, "bump", cfg["rstride"], fl, cfg["tailprio"])
+            gen_tile(E, kt % 3, kt % 2, DMA_PLANS[cfg["dma"]], 0, "bump", cfg["rstride"], fl, cfg["tailprio"], cfg["snake"])
         assert E.fifo == [], E.fifo
         if t < 5:
             E.branch("s_branch L_done_%=")
