@@ -368,27 +368,40 @@ def c_operands():
     return outs, ins
 
 
-def render():
+PRODUCT = (1, 2, 3)          # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
+OUT_DEV = os.path.join(ROOT, "protoquant_amd", "csrc", "kloop_p3_asm_dev.inc")
+ARGS = ("v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],\n"
+        "        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],\n"
+        "        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,\n"
+        "        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales, uint32_t half")
+CALL = "acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, nfull, sbw, phase, scale_src, sbs, do_scales, half"
+
+
+def render(vids, name, dev):
     out = []
     out.append("// GENERATED by tools/gen_kloop_asm.py -- do not edit; `python tools/gen_kloop_asm.py` rewrites it, tests/test_asm_guards.py")
     out.append("// checks that the committed file is what the generator produces.")
-    out.append("// kloop_p3_asm<V>: K-tiles 1 .. NT-1 of gemm_s8_sp256<..., P3 = true> (NT >= 5) as one hand-allocated asm statement:")
-    out.append("// nfull tiles that issue both DMA sides in a loop over ring turns, then the three closing tiles.  phase: position of the first tile")
-    out.append("// in the turn (0 behind the HIP code's tile 0; with immediate offsets the cursors come in moved back by phase * 128 bytes).")
-    out.append("// scale_src / sbs / do_scales: the per-lane source address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector")
-    out.append("// DMA, issued in the third tile from the end.")
+    if dev:
+        out.append("// Dev-only variants of kloop_p3_asm (timing ablations: results are wrong), compiled with -DPQ_ABLATION_BUILD.")
+    else:
+        out.append("// kloop_p3_asm<V>: K-tiles 1 .. NT-1 of gemm_s8_sp256<..., P3 = true> (NT >= 5) as one hand-allocated asm statement:")
+        out.append("// nfull tiles that issue both DMA sides in a loop over ring turns, then the three closing tiles.  phase: position of the first tile")
+        out.append("// in the turn (0 behind the HIP code's tile 0; with immediate offsets the cursors come in moved back by phase * 128 bytes).")
+        out.append("// scale_src / sbs / do_scales: the per-lane source address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector")
+        out.append("// DMA, issued in the third tile from the end.")
     out.append("#pragma once")
+    if not dev:
+        out.append("#ifdef PQ_ABLATION_BUILD")
+        out.append('#include "kloop_p3_asm_dev.inc"')
+        out.append("#endif")
     out.append("namespace pq {")
-    out.append("template <int V> __device__ __forceinline__ void kloop_p3_asm(v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],")
-    out.append("        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],")
-    out.append("        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,")
-    out.append("        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales, uint32_t half) {")
+    out.append(f"template <int V> __device__ __forceinline__ void {name}(" + ARGS + ") {")
     out.append("    uint64_t gp64 = reinterpret_cast<uint64_t>(gP), gq64 = reinterpret_cast<uint64_t>(gQ);")
     out.append("    uint32_t cnt = nfull;")
     outs, ins = c_operands()
     first = True
     mixes = {}
-    for vid in sorted(VARIANTS):
+    for vid in vids:
         E, per_tile = gen_variant(vid)
         mixes[vid] = per_tile
         out.append(f"    {'if' if first else 'else if'} constexpr (V == {vid}) {{")
@@ -402,7 +415,17 @@ def render():
         out.append('            : "memory", "scc");')
         out.append("    }")
         first = False
-    out.append("    else static_assert(V < 0, \"unknown K-loop variant\");")
+    if dev:
+        out.append("    else static_assert(V < 0, \"unknown K-loop variant\");")
+    else:
+        out.append("    else {")
+        out.append("#ifdef PQ_ABLATION_BUILD")
+        out.append("        kloop_p3_asm_dev<V>(" + CALL + ");")
+        out.append("        return;")
+        out.append("#else")
+        out.append("        static_assert(V < 0, \"unknown K-loop variant\");")
+        out.append("#endif")
+        out.append("    }")
     out.append("    gP = reinterpret_cast<const int8_t*>(gp64);")
     out.append("    gQ = reinterpret_cast<const int8_t*>(gq64);")
     out.append("}")
@@ -411,16 +434,21 @@ def render():
 
 
 def main():
-    text, mixes = render()
+    text, mixes = render([v for v in sorted(VARIANTS) if v in PRODUCT], "kloop_p3_asm", False)
+    text_dev, mixes_dev = render([v for v in sorted(VARIANTS) if v not in PRODUCT], "kloop_p3_asm_dev", True)
     if "--check" in sys.argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ""
-        if cur != text:
-            print("kloop_p3_asm.inc is stale: run python tools/gen_kloop_asm.py")
-            sys.exit(1)
+        for path, want in ((OUT, text), (OUT_DEV, text_dev)):
+            cur = open(path).read() if os.path.exists(path) else ""
+            if cur != want:
+                print(f"{os.path.basename(path)} is stale: run python tools/gen_kloop_asm.py")
+                sys.exit(1)
         return
     with open(OUT, "w") as f:
         f.write(text)
-    for vid, m in mixes.items():
+    with open(OUT_DEV, "w") as f:
+        f.write(text_dev)
+    mixes.update(mixes_dev)
+    for vid, m in sorted(mixes.items()):
         print(f"variant {vid} {VARIANTS[vid]}: loop, per K-tile per wave: " + ", ".join(f"{k} {v:g}" for k, v in sorted(m.items())))
 
 
