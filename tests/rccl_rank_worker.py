@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(rank)
+    torch.cuda.set_device(rank)       # (two ranks on ONE GPU are not an option: ncclCommInitRank refuses with "Duplicate GPU detected", tried on the pool's 1-GPU box)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import protoquant_amd as pq
     from protoquant_amd.sharded import shard_bounds
