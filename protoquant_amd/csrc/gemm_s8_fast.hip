@@ -221,27 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     }
 
     using acc_t = v4i;
-    acc_t acc[2][2][NPI][NQJ];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < NPI; ++i)
-#pragma unroll
-                for (int j = 0; j < NQJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < NACC; ++r) acc[a][b][i][j][r] = 0;
-    if constexpr (ASMV != 0) {   // keep the zeros in registers: folded into the C operand of the peeled tile 0, they cost that tile 64 more live registers (spills)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < NPI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NQJ; ++j) asm volatile("" : "+v"(acc[a][b][i][j]));
-    }
+    acc_t acc[2][2][NPI][NQJ];          // zeroed behind the prologue's DMA issue (below): 128 v_mov in front of the first piece were ~300 cycles of every tile's start
 
     v4i fPa[NPI][NKS], fPb[NPI][NKS], fQa[NQJ][NKS], fQb[NQJ][NKS];
     if constexpr (DBG) {   // defined operands when LDS reads are ablated
@@ -442,6 +422,22 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
             if (NT > 1) stage_tile(1);
             if (NBUF == 3 && NT > 2) stage_tile(2);
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                for (int j = 0; j < NQJ; ++j) {
+                    acc[a][b][i][j] = v4i{0, 0, 0, 0};
+                    // (asm K-loop kernels: keep the zeros in registers — folded into the C operand of the peeled tile 0 they cost that tile 64 more live registers: spills)
+                    if constexpr (ASMV != 0) asm volatile("" : "+v"(acc[a][b][i][j]));
+                }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!LC || loader) {
         // wait for the first half of tile 0 only (P0, Q0 — pieces are issued in need order P0 | Q0 | Q1 | P1): the rest of
         // tile 0 and the other staged tiles stay in flight
         if constexpr (no_vmwait) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
@@ -1046,11 +1042,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
         constexpr int it = decltype(ic)::value, ti = it & 3, ks = (it >> 2) & 1;
         f[it] = *reinterpret_cast<const v4i*>(smem + bufoff + (it < 8 ? lP[ks] : lQ[ks]) + ti * 16 * 128);
     };
-    v4i acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    v4i acc[4][4];                       // zeroed behind the prologue's DMA issue
 
     const int NT = K / FBK;
     // ---- prologue: up to 4 tiles in flight, wait for tile 0, read its fragments
@@ -1058,6 +1050,14 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
 #pragma unroll
         for (int b = 0; b < R_NBUF; ++b)
             if (b < NT) static_for<8>([&](auto gc) { dma_item(b, gc); });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    if (!LC || loader) {
         if (NT >= 4) __builtin_amdgcn_s_waitcnt(0x4078);        // vmcnt(24): 3 tiles may still be in flight
         else if (NT == 3) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
         else if (NT == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8)
