@@ -49,8 +49,13 @@ def _quant_rows(w: torch.Tensor, device):
 def convert_checkpoint(state_dict: dict, *, device="cuda", is_linear: Callable[[str, torch.Tensor], bool] = default_is_linear,
                        fuse: dict[str, Iterable[str]] | None = None, gated_mlp: Iterable[str] = (),
                        column_sharded: Iterable[str] = (), row_sharded: Iterable[str] = (), sharded_gated_mlp: Iterable[str] = (),
-                       world: int = 1, rank: int = 0, out_device="cpu") -> dict:
+                       world: int = 1, rank: int = 0, out_device="cpu", model: nn.Module | None = None) -> dict:
     """state_dict of float weights -> state_dict in FORMAT.
+
+    model: the FLOAT model the checkpoint belongs to (a meta-device instance is enough).  When given, exactly the weights of its
+      nn.Linear modules are quantised — the same criterion prepare_for_int8() / swap_linears() use on the loading side — instead of
+      the name / shape heuristic `is_linear` (which takes any 2-D float tensor that is not an embedding or a norm: a transposed
+      [in, out] weight such as GPT-2's Conv1D would be quantised along the wrong axis).
 
     fuse: ``{"layers.0.attn.qkv": ["layers.0.attn.q_proj", "layers.0.attn.k_proj", "layers.0.attn.v_proj"]}`` — the members
       are replaced by one FusedQLinear entry.  gated_mlp: prefixes of modules with gate_proj / up_proj / down_proj children
@@ -71,6 +76,9 @@ def convert_checkpoint(state_dict: dict, *, device="cuda", is_linear: Callable[[
                 return True
         return False
 
+    if model is not None:
+        linear_names = {n for n, m in model.named_modules() if isinstance(m, nn.Linear)}
+        is_linear = lambda name, w: name in linear_names      # noqa: E731
     sd = dict(state_dict)
     out = {}
     lin = {k[:-len(".weight")]: v for k, v in sd.items() if k.endswith(".weight") and is_linear(k[:-len(".weight")], v)}

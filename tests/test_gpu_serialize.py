@@ -172,3 +172,27 @@ def test_sharded_entries_load(pq, world):
     for p in partials[1:]:
         total = total + p
     assert torch.isfinite(total).all() and total.shape == (40, H)
+
+
+def test_convert_with_model_quantises_only_nn_linear(pq):
+    """with the float model given, convert_checkpoint quantises exactly the nn.Linear weights — a 2-D float parameter that is
+    not a Linear (here a [in, out] matrix, the GPT-2 Conv1D layout) stays float, where the name / shape heuristic would quantise it along
+    the wrong axis — and literal prefixes with regex metacharacters are compared literally."""
+    from protoquant_amd import serialize as S
+
+    class Odd(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(64, 48, bias=False)
+            self.conv1d_w = torch.nn.Parameter(torch.randn(64, 48))          # [in, out]: NOT an nn.Linear weight
+            self.blocks = torch.nn.ModuleDict({"a+b": torch.nn.Linear(48, 32, bias=True)})
+
+    m = Odd().to(torch.bfloat16)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["conv1d.weight"] = sd.pop("conv1d_w")                                  # a name the heuristic would take for a linear
+    conv = S.convert_checkpoint(sd, model=m, column_sharded=["blocks.a+b"], world=2, rank=1)
+    assert "proj.wq" in conv and conv["proj.wq"].dtype == torch.int8
+    assert "conv1d.weight" in conv and conv["conv1d.weight"].dtype == torch.bfloat16 and "conv1d.wq" not in conv
+    assert "blocks.a+b.local.wq" in conv and tuple(conv["blocks.a+b.local.wq"].shape) == (16, 48)       # rank 1 of 2: rows 16..31
+    heur = S.convert_checkpoint(sd)
+    assert "conv1d.wq" in heur                                                # what the heuristic alone does (documented, hence `model=`)
