@@ -243,6 +243,12 @@ DMA_PLANS = {
     "late": {52 + g: [g] for g in range(8)},
     # one piece every fourth MFMA over quadrants 2 and 3
     "even4": {33 + 4 * g: [g] for g in range(8)},
+    # placement sweep (profiles/r03_ab_asm_kloop.txt, run 6)
+    "q2dense": {33 + 2 * g: [g] for g in range(8)},
+    "q3dense": {48 + g: [g] for g in range(8)},
+    "alt4": {34 + 4 * g: [g] for g in range(8)},
+    "qearly": {33: [0], 36: [1], 39: [2], 42: [3], 52: [4], 55: [5], 58: [6], 61: [7]},
+    "bursts": {40: [0], 41: [1], 42: [2], 43: [3], 56: [4], 57: [5], 58: [6], 59: [7]},
 }
 
 
@@ -259,6 +265,8 @@ VARIANTS = {
     2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
     # (snake=True — boustrophedon MFMA order inside a quadrant, so that consecutive MFMAs always share one operand — measured +-0.2 %: profiles/r03_ab_asm_kloop.txt run 5)
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
+    # (the placement sweep of profiles/r03_ab_asm_kloop.txt run 6 — q2dense / q3dense / alt4 / qearly / bursts above — put "spread", "alt4" and "qearly" within
+    # 0.3 % of each other and the dense placements 2 - 4 % behind; the variants are not kept in the dev file)
     # timing only (wrong results), the ablations of round 2 on the asm loop: what the MFMA stream costs without its operand traffic
     6: V("spread", nodma=True),                    # no LDS-DMA (the fragment reads return stale LDS bytes)
     7: V("spread", nolds=True),                    # no fragment reads (the MFMAs run on whatever the registers hold)
