@@ -106,8 +106,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // kernel and come from the Infinity Cache: one K-tile of lead is enough for them.  No LDS of their own is left for the scale vectors:
 // they are DMA'd, two K-tiles before the epilogue, into the P slot that no later tile needs.
 // ASMV (P3 only): K-tiles 1 .. NT-4 run in the hand-allocated asm statement kloop_p3_asm<ASMV> (kloop_p3_asm.inc) instead of the HIP loop.
-template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0>   // ABL: compile-time ablation (0 = product)
-__global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
+// NCW (LC only): consumer waves, 4 or 8.  8: a 12-wave workgroup, three waves per SIMD (168 registers each) — the eight consumers take
+// 64 n x 64 m wave tiles (four 8-MFMA quadrants; 64 accumulator registers), two per SIMD, so one covers the other's operand and
+// barrier stalls the way the 256-row tile's two waves per SIMD do; the four loaders are unchanged.
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4>   // ABL: compile-time ablation (0 = product)
+__global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 : 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
     // ablation bits (dev builds only): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue, 16 direct epilogue
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         if constexpr (DBG) {
             if (stamps != nullptr) {
                 const unsigned long long r = __builtin_amdgcn_s_memrealtime(), c = __builtin_amdgcn_s_memtime();
-                if ((threadIdx.x & 63) == 0) {
+                if ((threadIdx.x & 63) == 0 && threadIdx.x < 512) {
                     unsigned long long* d = stamps + (((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + point) * 2;
                     d[0] = r; d[1] = c;
                 }
@@ -148,9 +151,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
     static_assert(ASMV == 0 || (P3 && (ABL == 0 || ABL == 1024)), "asm K-loop: split-ring tile only (dev builds: with stamps)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = LC && wave >= 4;
-    const int w = LC ? (wave & 3) : wave;               // index inside the role (issuer index for DMA pieces, consumer index for tiles)
+    static_assert(NCW == 4 || (LC && NCW == 8), "consumer waves");
+    const bool loader = LC && wave >= NCW;
+    const int w = LC ? (loader ? wave - NCW : wave) : wave;   // index inside the role (issuer index for DMA pieces, consumer index for tiles)
     constexpr int NWQ = LC ? 2 : 4;                      // consumer waves along m
+    constexpr int NWP = LC ? NCW / 2 : 2;                // ... along n
     constexpr int NISS = LC ? 4 : 8;                     // waves that issue DMA pieces
     const int wp = w / NWQ, wq = w % NWQ;
 
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
 
     static_assert(TM == 256 || TM == 128, "tile rows");
     static_assert(TN == 256 || (TN == 128 && TM == 128), "TN = 128 comes with TM = 128");
-    constexpr int PWH = TN / 4;                   // P rows per wave per half-tile: 64 or 32
+    constexpr int PWH = (TN / 2) / NWP;           // P rows per wave per half-tile: 64 or 32
     constexpr int PPW = (TN / 16) / NISS;         // DMA pieces per issuing wave per P half-tile (a P half-tile is TN/2 rows = TN/16 pieces)
     constexpr int QW = (TM / 2) / NWQ;            // Q rows per wave per half-tile: 32 or 16
     constexpr int QPW = (TM / 16) / NISS;         // DMA pieces per issuing wave per Q half-tile (a Q half-tile is TM/2 rows)
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_sp256(const int8_t* __restrict
         // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
         // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
         // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
-        constexpr int WREG = BUFB / (LC ? 4 : 8);                           // 8, 6 or 4 KiB (LC: 12 KiB for each of the 4 consumers)
+        constexpr int WREG = BUFB / (LC ? NCW : 8);                         // 8, 6 or 4 KiB (LC: 12 KiB for each of 4 consumers, 6 KiB for each of 8)
         // (P3: the P slot and the Q slot of tile NT-2 — read for the last time before a barrier every wave has passed, and no DMA
         // targets them again — four waves each; the third free slot, tile NT-3's P slot, holds the scales)
         const int last_slot = (NT - 1) % NBUF;
@@ -836,8 +841,9 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
-bool g_sp128_lc = true;     // loader / consumer split of the 128 x 256 tile (pq_set_option("PQ_SP128_LC", "0") restores the 8-wave form)
-void set_sp128_lc(bool v) { g_sp128_lc = v; }
+int g_sp128_lc = 1;         // loader / consumer split of the 128 x 256 tile: 1 = 4 consumers + 4 loaders; pq_set_option("PQ_SP128_LC", "0") restores
+                            // the 8-wave form (dev builds: 2 = 8 consumers + 4 loaders, 12 waves)
+void set_sp128_lc(int v) { g_sp128_lc = (v < 0 || v > 2) ? 1 : v; }
 // multi-round grids of the 256 x 256 tile through gemm_s8_p3_persist: OFF by default — bit-identical, race-screened, and measured 0 .. 1.7 % SLOWER than one workgroup
 // per tile (profiles/r03_ab_persistent.txt: the hardware dispatcher already overlaps a finished workgroup's store drain with its successor's prologue and
 // balances the tiles dynamically; the persistent form can prefetch only ONE K-tile under the epilogue — the rings are full — and then waits for the second)
@@ -854,6 +860,12 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
     if constexpr (TM == 128 && TN == 256) {
+#ifdef PQ_ABLATION_BUILD   // 12-wave form (8 consumers): measured 1-3 % slower warm, +-1 % HBM-fed (profiles/r03_ab_lc12.txt) — the tile is ingest-bound, not issue-bound
+        if (g_sp128_lc == 2) {
+            gemm_s8_sp256<OUT, 0, TM, TN, true, false, 0, 8><<<grid, dim3(768), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+            return;
+        }
+#endif
         if (g_sp128_lc) {
             gemm_s8_sp256<OUT, 0, TM, TN, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
             return;

@@ -28,7 +28,7 @@ void set_k1_rpw(int);
 void set_k1_st16(bool);
 void set_k1_lds(int);
 void set_ring_lc(bool);
-void set_sp128_lc(bool);
+void set_sp128_lc(int);
 void set_sp256_p3(bool);
 void set_sp256_asm(int);
 void set_sp256_persist(bool);
@@ -92,7 +92,7 @@ bool apply_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
-    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(!(value && *value == '0'));
+    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
     else if (!strcmp(name, "PQ_SP256_P3")) pq::set_sp256_p3(!(value && *value == '0'));
     else if (!strcmp(name, "PQ_SP256_ASM")) pq::set_sp256_asm(value && *value ? atoi(value) : -1);     // "" = default (1)
     else if (!strcmp(name, "PQ_SP256_PERSIST")) pq::set_sp256_persist(value && *value == '1');
