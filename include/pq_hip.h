@@ -46,7 +46,7 @@ int32_t pq_version(void);
 /* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
- * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same
+ * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same
  * names are read ONCE, at the first call into the library; this call changes a switch afterwards (process-wide, not
  * thread-safe against concurrent launches).  A captured hipGraph keeps the choice that was live at capture time. */
 int32_t pq_set_option(const char* name, const char* value);
@@ -139,7 +139,8 @@ int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void*
  * patterns whose stored silu(g) differs between the first two, counts[2] += between the last two.  counts[3] zeroed by the caller.  QSPEC S4. */
 int32_t pq_selftest_silu_short(int32_t dtype, unsigned long long* counts, void* stream);
 
-/* Name of the GEMM kernel variant the dispatcher would pick for this problem (static string). */
+/* Name of the single-pass GEMM kernel variant the dispatcher would pick for this problem (static string); with a workspace
+ * (pq_qlinear_workspace_bytes > 0) pq_qlinear_s8 runs split-K slices + a reduction pass instead. */
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 
 #ifdef __cplusplus

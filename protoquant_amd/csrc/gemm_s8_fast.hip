@@ -935,6 +935,12 @@ void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     EpiArgs epi{nullptr, nullptr, nullptr, slabs, N, 0};
+    if constexpr (TM == 256) {      // slices of at least five K-tiles: the split-ring tile with the asm K-loop
+        if (g_sp256_p3 && g_sp256_asm == 1 && K / kslices >= 5 * FBK) {
+            gemm_s8_sp256<OUT_I32, 0, 256, 256, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
+            return;
+        }
+    }
     gemm_s8_sp256<OUT_I32, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
 }
 template void launch_gemm_splitk_i32<256>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);

@@ -76,6 +76,7 @@ Variant parse_variant(const char* e) {
 struct Options {
     int variant = V_AUTO;
     bool no_tailsplit = false, no_splitk = false;
+    int force_splitk = 0;
     // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
     // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
     int (*roctx_push)(const char*) = nullptr;
@@ -84,12 +85,13 @@ struct Options {
 Options g_opt;
 std::once_flag g_opt_once;
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
+    else if (!strcmp(name, "PQ_FORCE_SPLITK")) g_opt.force_splitk = value && *value ? atoi(value) : 0;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
@@ -342,8 +344,13 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
 // 256 CUs even with 128-row tiles, K is long enough to amortise the extra pass, and the slices stay multiples of 128.
 static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     if (options().no_splitk) return 1;
+    if (options().force_splitk > 1 && M > 64 && K % (128 * options().force_splitk) == 0) { *tm_out = 256; return options().force_splitk; }   // (experiments)
     if (M <= 64 || N < 1 || K < 2048) return 1;    // (M <= 64: the skinny kernel splits K inside the workgroup)
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
+    // a quarter-filled 256 x 256 grid with a very long K (the Llama-70B `down` shard, 4096 x 1024 x 28672): four slices of the split-ring tile
+    // with the asm K-loop + the reduction pass tie with the ring tile when the weights are warm (100 us) and are immune to the feed (HBM-fed:
+    // 101 against 128 us, profiles/r03_ab_splitk_asm.txt); at K = 8192 the reduction pass costs more than the better loop returns (48 against 31 us)
+    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) { *tm_out = 256; return 4; }
     const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
     const int64_t tiles = tm == 128 ? t128 : t256;
     if (tiles > 128) return 1;
