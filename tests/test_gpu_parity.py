@@ -223,6 +223,28 @@ def test_splitk_bit_identical(pq, M, N, K, code, bias, pq_opt):
     same(pq.qlinear_s8(*args), want, "single-pass y")
 
 
+@pytest.mark.parametrize("M,N,S,NT,code,bias", [(300, 520, 2, 5, 0, True), (257, 256, 3, 7, 2, False), (512, 300, 4, 6, 1, True), (256, 512, 2, 8, 0, False),
+                                                 (640, 256, 2, 9, 0, True), (256, 777, 5, 10, 0, False), (130, 130, 2, 11, 2, True), (512, 512, 2, 4, 0, True)])
+def test_forced_splitk_slices_on_the_asm_loop(pq, M, N, S, NT, code, bias, pq_opt):
+    """PQ_FORCE_SPLITK: S slices of NT K-tiles each on the 256 x 256 split-ring tile — NT >= 5 runs the asm K-loop with int32 slab output (every ring
+    phase at the exit: NT = 5 .. 11), NT = 4 the 2-deep HIP ring — + the reduction pass, ragged M and N: == the oracle and == the single-pass kernel."""
+    from protoquant_amd import _lib
+    K = S * NT * 128
+    pq_opt("PQ_FORCE_SPLITK", str(S))
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == S * M * N * 4
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
+    acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)
+    want = Q.epilogue(acc, xs, ws, bv, code)
+    args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
+            to_gpu(bv, code) if bias else None, TD[code])
+    same(pq.qlinear_s8(*args), want, "forced split-K y")
+    pq_opt("PQ_FORCE_SPLITK", "")
+    same(pq.qlinear_s8(*args), want, "default dispatch y")
+
+
 @pytest.mark.parametrize("M", [1, 2, 7, 16, 17, 32, 33, 48, 64])
 @pytest.mark.parametrize("N,K", [(16, 128), (100, 256), (512, 1024), (4096, 4096), (1000, 2048), (37, 8192), (8192, 1024)])
 def test_skinny_gemm_exact(pq, M, N, K):
