@@ -78,6 +78,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// fused split-K workspace: bytes of the two per-tile counter arrays in front of the slabs
+__host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles) { return ((size_t)ntiles * 8 + 255) & ~(size_t)255; }
+
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -109,7 +112,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // NCW (LC only): consumer waves, 4 or 8.  8: a 12-wave workgroup, three waves per SIMD (168 registers each) — the eight consumers take
 // 64 n x 64 m wave tiles (four 8-MFMA quadrants; 64 accumulator registers), two per SIMD, so one covers the other's operand and
 // barrier stalls the way the 256-row tile's two waves per SIMD do; the four loaders are unchanged.
-template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4>   // ABL: compile-time ablation (0 = product)
+// FSK (P3 + ASMV only): FUSED split-K.  kslices workgroups share one output tile, each over K / kslices; the first kslices - 1 to finish their
+// K-loop (an agent-scope ticket counter per tile) dump their 128 accumulator registers to a slab of the workspace (16 B per lane,
+// coalesced: the layout is the register file's, only the partner reads it) and leave; the last one waits until those slabs are complete
+// — their writers are past their K-loops, so the wait is bounded by a 256-KiB store, never by a workgroup that has not been scheduled —
+// adds them to its registers (integer sums commute: the bits do not depend on who is last) and runs the ordinary epilogue.  The hand-over is the
+// asm statement behind the K-loop's (fsk_tail_asm, registers pinned: tools/gen_kloop_asm.py gen_fsk_tail).  No second
+// pass over int32 slabs of the whole output, and half (or a quarter) of the slab traffic of the two-pass form.  `stamps` carries the
+// workspace: [tickets: ntiles u32][ready: ntiles u32] (zeroed by the launcher), padded to 256 B, then the slabs.
+// FSK = 2: the two-slice form, a SYMMETRIC exchange — workgroups 2 p and 2 p + 1 share tile p; each stores one column half of its partial sums,
+// waits for the partner's flag, adds the partner's half to the one it kept and runs the epilogue of that half (fsk_pair_asm): half the slab traffic
+// per CU, no idle CU, half an epilogue each.  (The wait is for a workgroup with the neighbouring id, dispatched with this one.)
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4, int FSK = 0>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 : 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
                                                         int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
@@ -149,6 +163,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     static_assert(!LC || (TM == 128 && TN == 256), "loader / consumer split: 128 x 256 tile only");
     static_assert(!P3 || (TM == 256 && TN == 256 && !LC), "split rings: 256 x 256 tile only");
     static_assert(ASMV == 0 || (P3 && (ABL == 0 || ABL == 1024)), "asm K-loop: split-ring tile only (dev builds: with stamps)");
+    static_assert(FSK == 0 || (P3 && ASMV != 0 && ABL == 0 && OUT != OUT_I32), "fused split-K: the asm split-ring kernel with a dequantising epilogue");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     static_assert(NCW == 4 || (LC && NCW == 8), "consumer waves");
@@ -163,9 +178,15 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     // split-K (int32 output only): blocks [s*ntiles, (s+1)*ntiles) own K-slice s and write their exact partial
     // accumulators to slab s of the output buffer; a separate kernel sums the slabs and applies the epilogue.
     const int ntiles_all = tiles_m * tiles_n;
-    const int kslice = (int)blockIdx.x / ntiles_all;
+    const int kslice = FSK == 2 ? ((int)blockIdx.x & 1) : (int)blockIdx.x / ntiles_all;
     const int Ks = K / kslices;                       // bytes of K per slice (a multiple of FBK)
-    int t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all);
+    int t;
+    if constexpr (FSK == 2) {      // partners 2 p, 2 p + 1 (neighbouring XCDs); pairs p, p + 4, p + 8 ... share the two XCDs: a contiguous run of tiles for them
+        const int p = (int)blockIdx.x >> 1, q4 = ntiles_all >> 2, r4 = ntiles_all & 3, grp = p & 3, idx = p >> 2;
+        t = (grp < r4 ? grp * (q4 + 1) : r4 * (q4 + 1) + (grp - r4) * q4) + idx;
+    } else {
+        t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all);
+    }
     constexpr int GM = 4;
     const int band = t / (GM * tiles_n);
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
@@ -320,8 +341,6 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     const int NT = Ks / FBK;
 
     // this wave's WM(m) x WN(n) block of the output tile (epilogue coordinates; D[row <-> n][col <-> m]: a lane holds 4 consecutive n)
-    const int dcol = lane & 15;                                             // m inside a Q tile
-    const int drow4 = (lane >> 4) * 4;                                      // first of 4 consecutive n
     constexpr int WM = 2 * QW;                                              // rows (m) of this wave's block: 64 or 32
     constexpr int WN = 2 * PWH;                                             // columns (n) of this wave's block: 128 or 64
     const int wm0 = m0 + wq * WM, wn0 = n0 + wp * WN;
@@ -490,8 +509,20 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             e0 = e0 + 3 < slim ? e0 : (slim >= 4 ? slim - 4 : 0);
             const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
             const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok && w < 2));   // ("s" operands must be provably uniform)
-            kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
+            kloop_p3_asm<FSK != 0 ? 4 : ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
                                0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
+            if constexpr (FSK == 1) {
+                // the hand-over: the first kslices - 1 workgroups of a tile to arrive END inside this statement, the last leaves it with the tile's sums
+                unsigned* const ctr = reinterpret_cast<unsigned*>(stamps);
+                const uint8_t* const slab0 = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all) + (size_t)t * (size_t)(kslices - 1) * (256 * 256 * 4);
+                fsk_tail_asm(acc, ctr + t, ctr + ntiles_all + t, slab0, (uint32_t)(kslices - 1), smem_base + (uint32_t)scale_off + 2048u, (uint32_t)wave);
+            } else if constexpr (FSK == 2) {
+                // the exchange: this workgroup leaves the statement with the tile's sums in accumulator half a = kslice
+                unsigned* const flags = reinterpret_cast<unsigned*>(stamps) + 2 * t;
+                const uint8_t* const slabs = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all) + (size_t)t * (256 * 256 * 4);
+                fsk_pair_asm(acc, flags + kslice, flags + (kslice ^ 1), slabs + (size_t)kslice * (128 * 256 * 4), slabs + (size_t)(kslice ^ 1) * (128 * 256 * 4),
+                             (uint32_t)wave, (uint32_t)kslice);
+            }
         }
     } else {
     while (kt + DEPTH < NT) { tile(kt, slot, qslot, yes, yes, yes); adv(); }
@@ -503,6 +534,15 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     }
 
     stamp(2);
+    // epilogue lane coordinates.  (FSK: from the exec mask, behind an opaque barrier — that kernel has no register left to carry a
+    // lane-derived value across the asm K-loop: hipcc spilled them, and 16 accumulators with them)
+    int lane_e = lane;
+    if constexpr (FSK != 0) {
+        lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_e));
+    }
+    const int dcol = lane_e & 15;                                           // m inside a Q tile
+    const int drow4 = (lane_e >> 4) * 4;                                    // first of 4 consecutive n
     // ---- K4 epilogue: D[row <-> n][col <-> m]; lane holds 4 consecutive n per register group.
     if (no_epi) {   // keep the accumulators live, write (almost) nothing
         int sink = 0;
@@ -522,86 +562,97 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
 
     using O = typename OutElem<OUT>::type;
     constexpr int OB = (int)sizeof(O);
-    O* y = reinterpret_cast<O*>(epi.y) + (int64_t)kslice * M * epi.ldy;   // slab of this K-slice (kslices == 1: the output itself)
+    O* y = reinterpret_cast<O*>(epi.y) + (FSK != 0 ? 0 : (int64_t)kslice * M * epi.ldy);   // slab of this K-slice (kslices == 1 or fused split-K: the output itself)
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     constexpr int NG = 1;
 
-    // staged path: whole block in range, 16-byte aligned rows
-    const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
-                        ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
-                        (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
-    if (staged) {
-        // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
-        // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
-        // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
-        constexpr int WREG = BUFB / (LC ? NCW : 8);                         // 8, 6 or 4 KiB (LC: 12 KiB for each of 4 consumers, 6 KiB for each of 8)
-        // (P3: the P slot and the Q slot of tile NT-2 — read for the last time before a barrier every wave has passed, and no DMA
-        // targets them again — four waves each; the third free slot, tile NT-3's P slot, holds the scales)
-        const int last_slot = (NT - 1) % NBUF;
-        const uint32_t sw_off = P3 ? (uint32_t)((w < 4 ? p_off((NT + 1) % 3) : q_off(NT % 2)) + (w & 3) * WREG)
-                                   : (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
-        constexpr int NPT = 2 * NPI, NQT = 2 * NQJ;                         // column / row tiles of the wave block
-        constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;      // staged rows of at most 256 bytes
-        constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
-        constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
-        static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= WREG, "epilogue staging region");
-        auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt / NPI][qt / NQJ][pt % NPI][qt % NQJ]; };
-        auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + qt * 16 + dcol]; };
-        auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + scale_off + 1024 + (wp * WN + pt * 16 + drow4) * 4); };
-        uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0);
-        const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0)) : nullptr;
-        PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane);
-        stamp(3);
-        return;
-    }
+    // (HALF = -1: the whole wave block; 0 / 1: one column half of it — the two-slice fused split-K finishes acc[HALF][..] only)
+    auto epilogue = [&](auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+        constexpr int COL0 = HALF < 0 ? 0 : HALF * PWH;             // first column of the half inside the wave block
+        // staged path: whole block in range, 16-byte aligned rows
+        const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
+                            ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+                            (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
+        if (staged) {
+            // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
+            // (its tile was consumed before a barrier every wave has passed) and no DMA targets it (the last NBUF tiles issue
+            // none), so a wave that finishes early starts its epilogue under the MFMAs of the slower ones: no barrier.
+            constexpr int WREG = BUFB / (LC ? NCW : 8);                         // 8, 6 or 4 KiB (LC: 12 KiB for each of 4 consumers, 6 KiB for each of 8)
+            // (P3: the P slot and the Q slot of tile NT-2 — read for the last time before a barrier every wave has passed, and no DMA
+            // targets them again — four waves each; the third free slot, tile NT-3's P slot, holds the scales)
+            const int last_slot = (NT - 1) % NBUF;
+            const uint32_t sw_off = P3 ? (uint32_t)((w < 4 ? p_off((NT + 1) % 3) : q_off(NT % 2)) + (w & 3) * WREG)
+                                       : (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
+            constexpr int NPT = (HALF < 0 ? 2 : 1) * NPI, NQT = 2 * NQJ;        // column / row tiles of the wave block (HALF >= 0: of its column half)
+            constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;      // staged rows of at most 256 bytes
+            constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
+            constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
+            static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= WREG, "epilogue staging region");
+            auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[HALF < 0 ? pt / NPI : HALF][qt / NQJ][pt % NPI][qt % NQJ]; };
+            auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + qt * 16 + dcol]; };
+            auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + scale_off + 1024 + (wp * WN + COL0 + pt * 16 + drow4) * 4); };
+            uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0 + COL0);
+            const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0 + COL0)) : nullptr;
+            PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane_e);
+            stamp(3);
+            return;
+        }
 
-    // direct path (edge tiles / unaligned y): guarded stores straight from registers
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
+        // direct path (edge tiles / unaligned y): guarded stores straight from registers
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
 #pragma unroll
-    for (int hQ = 0; hQ < 2; ++hQ)
+        for (int hQ = 0; hQ < 2; ++hQ)
 #pragma unroll
-        for (int j = 0; j < NQJ; ++j) {
-            const int m = wm0 + hQ * QW + j * SHAPE + dcol;
-            const bool mok = m < M;
-            float as = 1.0f;
-            if constexpr (OUT != OUT_I32) as = mok ? epi.a_scale[m] : 0.0f;
+            for (int j = 0; j < NQJ; ++j) {
+                const int m = wm0 + hQ * QW + j * SHAPE + dcol;
+                const bool mok = m < M;
+                float as = 1.0f;
+                if constexpr (OUT != OUT_I32) as = mok ? epi.a_scale[m] : 0.0f;
 #pragma unroll
-            for (int hP = 0; hP < 2; ++hP)
+                for (int hP = (HALF < 0 ? 0 : HALF); hP < (HALF < 0 ? 2 : HALF + 1); ++hP)
 #pragma unroll
-                for (int i = 0; i < NPI; ++i)
+                    for (int i = 0; i < NPI; ++i)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const int n = wn0 + hP * PWH + i * SHAPE + drow4 + 8 * g;
-                        if (!mok || n >= N) continue;
-                        const acc_t& c = acc[hP][hQ][i][j];
-                        O* dst = y + (int64_t)m * epi.ldy + n;
-                        if (n + 3 < N && vec_ok) {
-                            O o[4];
+                        for (int g = 0; g < NG; ++g) {
+                            const int n = wn0 + hP * PWH + i * SHAPE + drow4 + 8 * g;
+                            if (!mok || n >= N) continue;
+                            const acc_t& c = acc[hP][hQ][i][j];
+                            O* dst = y + (int64_t)m * epi.ldy + n;
+                            if (n + 3 < N && vec_ok) {
+                                O o[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float bs = 1.0f, bf = 0.0f;
-                                if constexpr (OUT != OUT_I32) {
-                                    bs = epi.b_scale[n + r];
-                                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
+                                for (int r = 0; r < 4; ++r) {
+                                    float bs = 1.0f, bf = 0.0f;
+                                    if constexpr (OUT != OUT_I32) {
+                                        bs = epi.b_scale[n + r];
+                                        if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
+                                    }
+                                    o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
                                 }
-                                o[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
-                            }
-                            if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
-                            else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
-                        } else {
+                                if constexpr (OB == 2) *reinterpret_cast<v2u*>(dst) = *reinterpret_cast<const v2u*>(o);
+                                else *reinterpret_cast<v4u*>(dst) = *reinterpret_cast<const v4u*>(o);
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (n + r >= N) continue;
-                                float bs = 1.0f, bf = 0.0f;
-                                if constexpr (OUT != OUT_I32) {
-                                    bs = epi.b_scale[n + r];
-                                    if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
+                                for (int r = 0; r < 4; ++r) {
+                                    if (n + r >= N) continue;
+                                    float bs = 1.0f, bf = 0.0f;
+                                    if constexpr (OUT != OUT_I32) {
+                                        bs = epi.b_scale[n + r];
+                                        if (has_bias) bf = load_bias<OUT>(epi.bias, (epi.flags & EPI_BIAS_ROWS) ? m : n + r);
+                                    }
+                                    dst[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
                                 }
-                                dst[r] = epi_convert<OUT>(c[g * 4 + r], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
                             }
                         }
-                    }
-        }
+            }
+    };
+    if constexpr (FSK == 2) {
+        if (kslice == 0) epilogue(std::integral_constant<int, 0>{});
+        else epilogue(std::integral_constant<int, 1>{});
+    } else {
+        epilogue(std::integral_constant<int, -1>{});
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -926,6 +977,26 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     }
     gemm_s8_sp256<OUT, 0, TM, TN><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
 }
+
+// ---- fused split-K (gemm_s8_sp256<..., FSK>): kslices workgroups per 256 x 256 tile, partial sums handed over inside the kernel
+size_t fsk_workspace_bytes(int64_t M, int64_t N, int kslices) {
+    const int64_t ntiles = ((M + 255) / 256) * ((N + 255) / 256);
+    return fsk_counter_bytes((int)ntiles) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
+}
+template <int OUT>
+void launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
+                     int kslices, void* workspace, hipStream_t st) {
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
+    (void)hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n), st);        // tickets and ready counts
+    const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
+    if (kslices == 2)
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, static_cast<unsigned long long*>(workspace), 2);
+    else
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, static_cast<unsigned long long*>(workspace), kslices);
+}
+template void launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template void launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template void launch_gemm_fsk<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 
 // ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
 // the slabs (exact) and applies QSPEC E1-E4.  Doubles/quadruples the busy CUs for small-MN / long-K problems.

@@ -22,6 +22,8 @@ template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
+template <int OUT> void launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+size_t fsk_workspace_bytes(int64_t, int64_t, int);
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
@@ -77,6 +79,7 @@ struct Options {
     int variant = V_AUTO;
     bool no_tailsplit = false, no_splitk = false;
     int force_splitk = 0;
+    int fsk = 0;             // fused split-K: S > 1 = S slices whenever the shape admits them (opt-in; see fsk_plan)
     // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
     // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
     int (*roctx_push)(const char*) = nullptr;
@@ -85,13 +88,14 @@ struct Options {
 Options g_opt;
 std::once_flag g_opt_once;
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
     else if (!strcmp(name, "PQ_FORCE_SPLITK")) g_opt.force_splitk = value && *value ? atoi(value) : 0;
+    else if (!strcmp(name, "PQ_FSK")) g_opt.fsk = value && *value ? atoi(value) : 0;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
@@ -364,7 +368,19 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     return s;
 }
 
+// fused split-K (gemm_s8_sp256<..., FSK>: the partial sums of a tile's K-slices are handed over inside the GEMM kernel): OPT-IN, PQ_FSK=S.  Built for the
+// half-filled 256 x 256 grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008) and measured (profiles/r03_ab_fsk.txt): alone, weights from HBM, 77 against
+// 83 us for the 128 x 256 tile; weights warm 72 against 67 us; inside the MLP block +-1 %.  The four-slice form ties with the two-pass split-K on the 70B
+// `down` shard.  Not chosen by any plan: returns the slice count only when PQ_FSK asks for it and the shape admits it.
+static int fsk_plan(int64_t M, int64_t N, int64_t K) {
+    const int f = options().fsk;
+    if (f <= 1 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
+    (void)N;
+    return (K % (128 * f) == 0 && K / f >= 5 * 128) ? f : 0;
+}
+
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (const int f = fsk_plan(M, N, K)) return pq::fsk_workspace_bytes(M, N, f);
     int tm = 256;
     const int s = splitk_plan(M, N, K, &tm);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(int32_t) : 0;
@@ -377,8 +393,21 @@ static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, cons
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.
+    const bool tiled = (v == V_SP256_16 || v == V_SP128_16 || v == V_RING128) && forced_variant() == V_AUTO;
+    if (const int f = tiled ? fsk_plan(M, N, K) : 0; f > 1 && workspace != nullptr) {
+        const size_t need = pq::fsk_workspace_bytes(M, N, f);
+        if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "%s: workspace must be 16-byte aligned", what);
+        if (!pq::epi_flags_valid(epi.flags, epi.bias != nullptr)) abort();
+        switch (out_dtype) {
+            case PQ_BF16: pq::launch_gemm_fsk<PQ_BF16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+            case PQ_FP16: pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+            default: pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+        }
+        return check_launch(what);
+    }
     int tm = 256;
-    const int ks = (v == V_SP256_16 || v == V_SP128_16 || v == V_RING128) && forced_variant() == V_AUTO ? splitk_plan(M, N, K, &tm) : 1;
+    const int ks = tiled && fsk_plan(M, N, K) == 0 ? splitk_plan(M, N, K, &tm) : 1;
     if (ks > 1 && workspace != nullptr) {
         const size_t need = (size_t)ks * (size_t)M * (size_t)N * sizeof(int32_t);
         if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);

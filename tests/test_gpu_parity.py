@@ -245,6 +245,34 @@ def test_forced_splitk_slices_on_the_asm_loop(pq, M, N, S, NT, code, bias, pq_op
     same(pq.qlinear_s8(*args), want, "default dispatch y")
 
 
+@pytest.mark.parametrize("M,N,S,NT,code,bias", [(300, 520, 2, 5, 0, True), (257, 256, 3, 7, 2, False), (512, 300, 4, 6, 1, True), (256, 512, 2, 8, 0, False),
+                                                 (640, 256, 2, 9, 0, True), (256, 777, 5, 10, 0, False), (130, 130, 2, 11, 2, True), (2048, 4096, 2, 43, 0, False),
+                                                 (1024, 1024, 4, 16, 1, True), (2048, 4096, 2, 43, 0, True)])
+def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
+    """PQ_FSK=S (opt-in): the K-slices of a 256 x 256 tile hand their partial sums over INSIDE the GEMM kernel — S = 2: the symmetric exchange between
+    workgroups 2 p and 2 p + 1 (each finishes one column half), S > 2: the ticket form (the last workgroup of a tile to arrive adds the others' slabs);
+    every ring phase at the exit (NT = 5 .. 11), ragged M and N (edge tiles through the direct epilogue), a full-size half-filled grid (the cfg-3 `down`
+    GEMM, all 256 CUs in the exchange at once), repeated calls on one workspace (the launcher re-zeroes the flags): == the oracle and == the default dispatch."""
+    from protoquant_amd import _lib
+    K = S * NT * 128
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
+    args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
+            to_gpu(bv, code) if bias else None, TD[code])
+    y_def = pq.qlinear_s8(*args)
+    if M * N <= 1 << 20:
+        acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)
+        same(y_def, Q.epilogue(acc, xs, ws, bv, code), "default dispatch y")
+    pq_opt("PQ_FSK", str(S))
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == ((tiles * 8 + 255) // 256) * 256 + tiles * (S - 1) * 256 * 256 * 4
+    for _ in range(3):
+        y = pq.qlinear_s8(*args)
+        assert torch.equal(y.view(torch.uint8), y_def.view(torch.uint8)), "fused split-K y"
+
+
 @pytest.mark.parametrize("M", [1, 2, 7, 16, 17, 32, 33, 48, 64])
 @pytest.mark.parametrize("N,K", [(16, 128), (100, 256), (512, 1024), (4096, 4096), (1000, 2048), (37, 8192), (8192, 1024)])
 def test_skinny_gemm_exact(pq, M, N, K):

@@ -255,9 +255,10 @@ DMA_PLANS = {
 # variant id -> dict(dma: plan of waves 0-3, dma_b: plan of waves 4-7 (None = same code), align8, nowait, nobar,
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
-def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False, snake=False):
+def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False, snake=False,
+      pinacc=False):
     return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio, nodma=nodma, nolds=nolds,
-                nowalk=nowalk, snake=snake)
+                nowalk=nowalk, snake=snake, pinacc=pinacc)
 
 
 VARIANTS = {
@@ -265,6 +266,7 @@ VARIANTS = {
     2: V("hip", ptr="bump"),                       # the HIP loop's placement and cursor handling, for A/B runs
     # (snake=True — boustrophedon MFMA order inside a quadrant, so that consecutive MFMAs always share one operand — measured +-0.2 %: profiles/r03_ab_asm_kloop.txt run 5)
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
+    4: V("spread", pinacc=True),                   # the product loop with the accumulators PINNED where fsk_tail_asm wants them (gemm_s8_sp256<..., FSK>)
     # (the placement sweep of profiles/r03_ab_asm_kloop.txt run 6 — q2dense / q3dense / alt4 / qearly / bursts above — put "spread", "alt4" and "qearly" within
     # 0.3 % of each other and the dense placements 2 - 4 % behind; the variants are not kept in the dev file)
     # timing only (wrong results), the ablations of round 2 on the asm loop: what the MFMA stream costs without its operand traffic
@@ -350,13 +352,186 @@ def gen_variant(vid):
     return E, per_tile
 
 
-def c_operands():
+# ---- fused split-K tail (variant 4).  The statement's vector operands are PINNED for this variant (accumulator group g = v[128+4g : 131+4g],
+# fragments v[32:127]) so that the tail can name single registers: inline asm has no sub-register syntax, and left to hipcc the hand-over code
+# (32 slab addresses, the loads in flight) was allocated on top of the 128 accumulators and spilled — also inside tile 0, where a scratch access
+# breaks the counted vmcnt waits.  Protocol (the agent-scope instruction sequences are the ones hipcc emits for the HIP atomics / fences):
+#   ticket = atomic_add(tick, 1) by one lane, broadcast through LDS;
+#   ticket < nsl (not the last of the nsl + 1 slices): store the 128 accumulator registers to slab `ticket` (register-file layout: group g of wave w
+#     at ((w * 32 + g) * 64 + lane) * 16) with WRITE-THROUGH (sc1) stores, wait for their acknowledgements, barrier, atomic_add(ready, 1), END THE WAVE;
+#   the last: poll ready (sc1 load) until it reaches nsl, then per slab 23 agent-scope (sc1) loads in flight into the dead fragment registers and 4
+#     v_add_u32 per group.  (A first version used hipcc's fence sequences — buffer_wbl2 sc1 / buffer_inv sc1 in every wave — and lost 35 us per launch to them.)
+FSK_ACC0, FSK_TMP0, FSK_NTMP = 128, 32, 23
+FSK_T = ("v124", "v125", "v126")        # 32-bit temporaries (the 24th fragment quad)
+
+
+def gen_fsk_tail(E):
+    def R(text, size=4):
+        E.raw(text, size, "fsk")
+    t0, t1, t2 = FSK_T
+    accq = lambda g: f"v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]"
+    tmpq = lambda q: f"v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]"
+    off = lambda g: (f" offset:{(g % 4) * 1024}" if g % 4 else "")
+    R(f"v_mbcnt_lo_u32_b32 {t0}, -1, 0", 8)
+    R(f"v_mbcnt_hi_u32_b32 {t0}, -1, {t0}", 8)
+    R(f"v_lshlrev_b32 {t0}, 4, {t0}")
+    R("s_lshl_b32 %[st0], %[wv], 15")
+    R(f"v_add_u32 {t0}, %[st0], {t0}")                       # t0 = wave * 32 KiB + lane * 16
+    R("s_cmp_lg_u32 %[wv], 0")
+    R("s_cbranch_scc1 L_fsk_tk_%=")
+    R("s_mov_b64 %[sx], exec")
+    R("s_mov_b64 exec, 1")
+    R(f"v_mov_b32 {t1}, 1")
+    R(f"v_mov_b32 {t2}, 0")
+    R(f"global_atomic_add {t1}, {t2}, {t1}, %[tick] sc0", 8)
+    R("s_waitcnt vmcnt(0)")
+    R(f"v_mov_b32 {t2}, %[tkl]")
+    R(f"ds_write_b32 {t2}, {t1}", 8)
+    R("s_waitcnt lgkmcnt(0)")
+    R("s_mov_b64 exec, %[sx]")
+    E.label("L_fsk_tk_%=")
+    R("s_barrier")
+    R(f"v_mov_b32 {t2}, %[tkl]")
+    R(f"ds_read_b32 {t1}, {t2}", 8)
+    R("s_waitcnt lgkmcnt(0)")
+    R(f"v_readfirstlane_b32 %[st0], {t1}")                   # the ticket
+    R("s_cmp_ge_u32 %[st0], %[nsl]")
+    R("s_cbranch_scc1 L_fsk_last_%=")
+    # ---- not the last arriver
+    R("s_lshl_b32 %[st1], %[st0], 18")                       # slab `ticket`: 256 KiB each
+    R(f"v_add_u32 {t0}, %[st1], {t0}")
+    for g in range(32):
+        R(f"global_store_dwordx4 {t0}, {accq(g)}, %[slab]" + off(g) + " sc1", 8)
+        if g % 4 == 3 and g < 31:
+            R(f"v_add_u32 {t0}, 0x1000, {t0}", 8)
+    R("s_waitcnt vmcnt(0)")                                  # (write-through stores: acknowledged = visible to the agent; no L2 write-back needed)
+    R("s_barrier")
+    R("s_cmp_lg_u32 %[wv], 0")
+    R("s_cbranch_scc1 L_fsk_end_%=")
+    R("s_mov_b64 exec, 1")
+    R(f"v_mov_b32 {t1}, 1")
+    R(f"v_mov_b32 {t2}, 0")
+    R(f"global_atomic_add {t2}, {t1}, %[rdy]", 8)
+    R("s_waitcnt vmcnt(0)")
+    E.label("L_fsk_end_%=")
+    R("s_endpgm")
+    # ---- the last arriver
+    E.label("L_fsk_last_%=")
+    R("s_cmp_lg_u32 %[wv], 0")
+    R("s_cbranch_scc1 L_fsk_polled_%=")
+    R("s_mov_b64 %[sx], exec")
+    R("s_mov_b64 exec, 1")
+    R(f"v_mov_b32 {t2}, 0")
+    E.label("L_fsk_poll_%=")
+    R(f"global_load_dword {t1}, {t2}, %[rdy] sc1", 8)
+    R("s_waitcnt vmcnt(0)")
+    R(f"v_readfirstlane_b32 %[st1], {t1}")
+    R("s_cmp_ge_u32 %[st1], %[nsl]")
+    R("s_cbranch_scc1 L_fsk_polldone_%=")
+    R("s_sleep 8")
+    R("s_branch L_fsk_poll_%=")
+    E.label("L_fsk_polldone_%=")
+    R("s_mov_b64 exec, %[sx]")
+    E.label("L_fsk_polled_%=")
+    R("s_barrier")
+    R("s_mov_b32 %[st1], 0")                                 # (the slab loads are agent-scope loads themselves: no cache invalidate)
+    E.label("L_fsk_slab_%=")
+    R("s_lshl_b32 %[st0], %[st1], 18")
+    R(f"v_add_u32 {t1}, %[st0], {t0}")                       # running address: slab st1, group 0
+    issued = 0
+
+    def load(g):
+        nonlocal issued
+        if g and g % 4 == 0:
+            R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
+        R(f"global_load_dwordx4 {tmpq(g % FSK_NTMP)}, {t1}, %[slab]" + off(g) + " sc1", 8)
+        issued += 1
+    for g in range(FSK_NTMP):
+        load(g)
+    for j in range(32):
+        R(f"s_waitcnt vmcnt({issued - 1 - j})")
+        q = j % FSK_NTMP
+        for r in range(4):
+            R(f"v_add_u32 v{FSK_ACC0 + 4 * j + r}, v{FSK_ACC0 + 4 * j + r}, v{FSK_TMP0 + 4 * q + r}")
+        if j + FSK_NTMP < 32:
+            load(j + FSK_NTMP)
+    R("s_add_u32 %[st1], %[st1], 1")
+    R("s_cmp_lt_u32 %[st1], %[nsl]")
+    R("s_cbranch_scc1 L_fsk_slab_%=")
+
+
+# ---- the two-slice form: a SYMMETRIC exchange.  Workgroup s of the pair keeps accumulator half a = s (groups 16 s .. 16 s + 15: the output columns
+# hP = s of every wave block), stores the other half to its own slab (128 KiB, write-through), raises its flag, waits for the partner's flag, adds the
+# partner's half-slab to the half it keeps and runs the epilogue of that half: half the slab traffic per CU, both CUs busy, half an epilogue each.
+# The wait is for a workgroup that may not have started yet: the launcher numbers the partners 2 p and 2 p + 1, so that they are dispatched together.
+def gen_fsk_pair_tail(E):
+    def R(text, size=4):
+        E.raw(text, size, "fsk")
+    t0, t1, t2 = FSK_T
+    accq = lambda g: f"v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]"
+    tmpq = lambda q: f"v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]"
+    off = lambda k: (f" offset:{(k % 4) * 1024}" if k % 4 else "")
+    R(f"v_mbcnt_lo_u32_b32 {t0}, -1, 0", 8)
+    R(f"v_mbcnt_hi_u32_b32 {t0}, -1, {t0}", 8)
+    R(f"v_lshlrev_b32 {t0}, 4, {t0}")
+    R("s_lshl_b32 %[st0], %[wv], 14")
+    R(f"v_add_u32 {t0}, %[st0], {t0}")                       # t0 = wave * 16 KiB + lane * 16
+    R("s_cmp_lg_u32 %[sl], 0")
+    R("s_cbranch_scc1 L_fskp_s1_%=")
+    for sl in (0, 1):
+        keep0, send0 = 16 * sl, 16 * (1 - sl)
+        if sl:
+            E.label("L_fskp_s1_%=")
+        R(f"v_mov_b32 {t1}, {t0}")
+        for k in range(16):
+            if k and k % 4 == 0:
+                R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
+            R(f"global_store_dwordx4 {t1}, {accq(send0 + k)}, %[mslab]" + off(k) + " sc1", 8)
+        R("s_waitcnt vmcnt(0)")
+        R("s_barrier")
+        R("s_cmp_lg_u32 %[wv], 0")
+        R(f"s_cbranch_scc1 L_fskp_w{sl}_%=")
+        R("s_mov_b64 %[sx], exec")
+        R("s_mov_b64 exec, 1")
+        R(f"v_mov_b32 {t1}, 1")
+        R(f"v_mov_b32 {t2}, 0")
+        R(f"global_atomic_add {t2}, {t1}, %[mflag]", 8)
+        E.label(f"L_fskp_poll{sl}_%=")
+        R(f"global_load_dword {t1}, {t2}, %[pflag] sc1", 8)
+        R("s_waitcnt vmcnt(0)")
+        R(f"v_readfirstlane_b32 %[st1], {t1}")
+        R("s_cmp_ge_u32 %[st1], 1")
+        R(f"s_cbranch_scc1 L_fskp_pd{sl}_%=")
+        R("s_sleep 4")
+        R(f"s_branch L_fskp_poll{sl}_%=")
+        E.label(f"L_fskp_pd{sl}_%=")
+        R("s_mov_b64 exec, %[sx]")
+        E.label(f"L_fskp_w{sl}_%=")
+        R("s_barrier")
+        R(f"v_mov_b32 {t1}, {t0}")
+        for k in range(16):
+            if k and k % 4 == 0:
+                R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
+            R(f"global_load_dwordx4 {tmpq(k)}, {t1}, %[pslab]" + off(k) + " sc1", 8)
+        for k in range(16):
+            R(f"s_waitcnt vmcnt({15 - k})")
+            for r in range(4):
+                R(f"v_add_u32 v{FSK_ACC0 + 4 * (keep0 + k) + r}, v{FSK_ACC0 + 4 * (keep0 + k) + r}, v{FSK_TMP0 + 4 * k + r}")
+        if sl == 0:
+            R("s_branch L_fskp_end_%=")
+    E.label("L_fskp_end_%=")
+
+
+def c_operands(pinacc=False):
     outs, ins = [], []
+    g = 0
     for a in range(2):
         for b in range(2):
             for i in range(4):
                 for j in range(2):
-                    outs.append(f'[{acc(a, b, i, j)}] "+v"(acc[{a}][{b}][{i}][{j}])')
+                    con = f"+{{v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]}}" if pinacc else "+v"
+                    outs.append(f'[{acc(a, b, i, j)}] "{con}"(acc[{a}][{b}][{i}][{j}])')
+                    g += 1
     for name, var, n in (("pa", "fPa", 4), ("pb", "fPb", 4), ("qa", "fQa", 2), ("qb", "fQb", 2)):
         for i in range(n):
             for ks in range(2):
@@ -376,7 +551,53 @@ def c_operands():
     return outs, ins
 
 
-PRODUCT = (1, 2, 3)          # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
+def _render_tail(name, doc, gen, args, ins):
+    E = Emitter(False, False, False)
+    E.raw("s_nop 7", 4, "s_nop")
+    gen(E)
+    out = list(doc)
+    out.append(f"__device__ __forceinline__ void {name}(v4i (&acc)[2][2][4][2], {args}) {{")
+    out.append("    uint32_t fsk_st0, fsk_st1; uint64_t fsk_sx;")
+    out.append(f"    v4i tmp[{FSK_NTMP + 1}];")
+    out.append("    asm volatile(")
+    for l in E.lines:
+        out.append('        "' + l + '\\n\\t"')
+    outs = []
+    g = 0
+    for a in range(2):
+        for b in range(2):
+            for i in range(4):
+                for j in range(2):
+                    outs.append(f'"+{{v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]}}"(acc[{a}][{b}][{i}][{j}])')
+                    g += 1
+    for q in range(FSK_NTMP + 1):
+        outs.append(f'"=&{{v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]}}"(tmp[{q}])')
+    outs += ['[st0] "=&s"(fsk_st0)', '[st1] "=&s"(fsk_st1)', '[sx] "=&s"(fsk_sx)']
+    out.append("        : " + ",\n          ".join(outs))
+    out.append("        : " + ",\n          ".join(ins))
+    out.append('        : "memory", "scc");')
+    out.append("    (void)tmp; (void)fsk_st0; (void)fsk_st1; (void)fsk_sx;")
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def render_fsk_tail():
+    """the fused split-K hand-overs as statements of their own behind the K-loop statement (gemm_s8_sp256<..., FSK>)"""
+    doc = ["// fsk_tail_asm: the hand-over of fused split-K, any number of slices (see gen_fsk_tail in tools/gen_kloop_asm.py).  Accumulator group g is",
+           f"// pinned to v[{FSK_ACC0}+4g : {FSK_ACC0 + 3}+4g], the {FSK_NTMP + 1} quads v[{FSK_TMP0}:{FSK_TMP0 + 4 * (FSK_NTMP + 1) - 1}] are the statement's temporaries.  A workgroup that is not the last of",
+           "// its tile to arrive ENDS inside the statement."]
+    a = _render_tail("fsk_tail_asm", doc, gen_fsk_tail,
+                     "const void* fsk_tick, const void* fsk_ready, const void* fsk_slab,\n        uint32_t fsk_nsl, uint32_t fsk_lds, uint32_t fsk_wave",
+                     ['[tick] "s"(fsk_tick)', '[rdy] "s"(fsk_ready)', '[slab] "s"(fsk_slab)', '[nsl] "s"(fsk_nsl)', '[tkl] "s"(fsk_lds)', '[wv] "s"(fsk_wave)'])
+    doc = ["// fsk_pair_asm: the symmetric exchange of the two-slice form (gen_fsk_pair_tail): slice s leaves the statement with the tile's sums in",
+           "// accumulator half a = s (groups 16 s .. 16 s + 15); the other half is dead."]
+    b = _render_tail("fsk_pair_asm", doc, gen_fsk_pair_tail,
+                     "const void* my_flag, const void* peer_flag, const void* my_slab, const void* peer_slab,\n        uint32_t fsk_wave, uint32_t fsk_slice",
+                     ['[mflag] "s"(my_flag)', '[pflag] "s"(peer_flag)', '[mslab] "s"(my_slab)', '[pslab] "s"(peer_slab)', '[wv] "s"(fsk_wave)', '[sl] "s"(fsk_slice)'])
+    return a + b
+
+
+PRODUCT = (1, 2, 3, 4)         # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
 OUT_DEV = os.path.join(ROOT, "protoquant_amd", "csrc", "kloop_p3_asm_dev.inc")
 ARGS = ("v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],\n"
         "        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],\n"
@@ -411,6 +632,7 @@ def render(vids, name, dev):
     mixes = {}
     for vid in vids:
         E, per_tile = gen_variant(vid)
+        outs, ins = c_operands(VARIANTS[vid]["pinacc"])
         mixes[vid] = per_tile
         out.append(f"    {'if' if first else 'else if'} constexpr (V == {vid}) {{")
         out.append(f"        // {VARIANTS[vid]}")
@@ -437,6 +659,8 @@ def render(vids, name, dev):
     out.append("    gP = reinterpret_cast<const int8_t*>(gp64);")
     out.append("    gQ = reinterpret_cast<const int8_t*>(gq64);")
     out.append("}")
+    if not dev:
+        out.append(render_fsk_tail().rstrip("\n"))
     out.append("}  // namespace pq")
     return "\n".join(out) + "\n", mixes
 
