@@ -10,7 +10,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("cfgs", nargs="*", default=["-"])
 ap.add_argument("--rows", type=int, default=4096)
 ap.add_argument("--cols", type=int, default=4096)
+ap.add_argument("--lib", default=None, help="another build of libpq_hip.so (A/B across processes)")
 a = ap.parse_args()
+if a.lib:
+    LL.LIB_PATH = os.path.abspath(a.lib)
 L = LL.lib()
 M, K, N = a.rows, a.cols, 4096
 dev = "cuda"
