@@ -46,8 +46,8 @@ int32_t pq_version(void);
 /* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
- * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (slices of the
- * opt-in fused split-K), PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the
+ * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
+ * split-K, S = S slices), PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the
  * first call into the library; this call changes a switch afterwards (process-wide, not thread-safe against concurrent launches).  A captured hipGraph keeps the choice that was live at capture time. */
 int32_t pq_set_option(const char* name, const char* value);
 

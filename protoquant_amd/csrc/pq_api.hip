@@ -79,7 +79,7 @@ struct Options {
     int variant = V_AUTO;
     bool no_tailsplit = false, no_splitk = false;
     int force_splitk = 0;
-    int fsk = 0;             // fused split-K: S > 1 = S slices whenever the shape admits them (opt-in; see fsk_plan)
+    int fsk = -1;            // fused split-K: -1 = by plan (fsk_plan), 0 = never, S > 1 = S slices whenever the shape admits them (experiments)
     // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
     // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
     int (*roctx_push)(const char*) = nullptr;
@@ -95,7 +95,7 @@ bool apply_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
     else if (!strcmp(name, "PQ_FORCE_SPLITK")) g_opt.force_splitk = value && *value ? atoi(value) : 0;
-    else if (!strcmp(name, "PQ_FSK")) g_opt.fsk = value && *value ? atoi(value) : 0;
+    else if (!strcmp(name, "PQ_FSK")) g_opt.fsk = value && *value ? atoi(value) : -1;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
@@ -368,15 +368,17 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     return s;
 }
 
-// fused split-K (gemm_s8_sp256<..., FSK>: the partial sums of a tile's K-slices are handed over inside the GEMM kernel): OPT-IN, PQ_FSK=S.  Built for the
-// half-filled 256 x 256 grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008) and measured (profiles/r03_ab_fsk.txt): alone, weights from HBM, 77 against
-// 83 us for the 128 x 256 tile; weights warm 72 against 67 us; inside the MLP block +-1 %.  The four-slice form ties with the two-pass split-K on the 70B
-// `down` shard.  Not chosen by any plan: returns the slice count only when PQ_FSK asks for it and the shape admits it.
+// fused split-K (gemm_s8_sp256<..., FSK>: the partial sums of a tile's K-slices are handed over inside the GEMM kernel).  Chosen for the half-filled 256 x 256
+// grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008): two workgroups per tile, symmetric exchange.  Measured against the 128 x 256 tile
+// (profiles/r03_ab_fsk.txt, run 5): weights from HBM — what a layer inside a model sees — 73.5 against 84.1 us (K = 14336: 90.7 against 98.8; 16384: 101.4
+// against 105.7); weights warm 71.8 against 68.4 us (88.4 / 87.4, 99.1 / 99.4).  PQ_FSK=0 turns it off, PQ_FSK=S (experiments) forces S slices wherever the
+// shape admits them (S > 2: the ticket form, which ties with the two-pass split-K on the 70B `down` shard and is not chosen by the plan).
 static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     const int f = options().fsk;
-    if (f <= 1 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
-    (void)N;
-    return (K % (128 * f) == 0 && K / f >= 5 * 128) ? f : 0;
+    if (f == 0 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
+    if (f > 1) return (K % (128 * f) == 0 && K / f >= 5 * 128) ? f : 0;
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    return (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) ? 2 : 0;
 }
 
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -106,16 +106,9 @@ def test_split_ring_gemm_does_not_spill(code_objects):
             if not m:
                 continue
             seen += 1
-            if re.search(r"ELi4ELi[12]EEEv", m.group(1)):
-                # the opt-in fused split-K instantiations (template argument FSK = 1 / 2): their accumulators are pinned for the hand-over statement and
-                # hipcc spills a few registers in the HIP-coded K-tile 0 (once per output tile; extra vector-memory operations only make the counted
-                # waits stricter).  Bounded here; the asm K-loop itself cannot spill.
-                sz = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
-                assert sz <= 128, f"{m.group(1)}: {sz} bytes of scratch"
-                continue
             assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), f"{m.group(1)} uses scratch"
             assert re.search(r"\.vgpr_spill_count:\s+0\b", blk), f"{m.group(1)} spills VGPRs"
-    assert seen >= 8
+    assert seen >= 14          # (incl. the six fused split-K instantiations: their pinned registers are hipcc's own assignment of the product kernel)
 
 
 def test_generated_kloop_is_current():

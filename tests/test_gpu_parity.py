@@ -249,7 +249,7 @@ def test_forced_splitk_slices_on_the_asm_loop(pq, M, N, S, NT, code, bias, pq_op
                                                  (640, 256, 2, 9, 0, True), (256, 777, 5, 10, 0, False), (130, 130, 2, 11, 2, True), (2048, 4096, 2, 43, 0, False),
                                                  (1024, 1024, 4, 16, 1, True), (2048, 4096, 2, 43, 0, True)])
 def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
-    """PQ_FSK=S (opt-in): the K-slices of a 256 x 256 tile hand their partial sums over INSIDE the GEMM kernel — S = 2: the symmetric exchange between
+    """PQ_FSK=S (forced here; the plan picks S = 2 for half-filled grids with a long K): the K-slices of a 256 x 256 tile hand their partial sums over INSIDE the GEMM kernel — S = 2: the symmetric exchange between
     workgroups 2 p and 2 p + 1 (each finishes one column half), S > 2: the ticket form (the last workgroup of a tile to arrive adds the others' slabs);
     every ring phase at the exit (NT = 5 .. 11), ragged M and N (edge tiles through the direct epilogue), a full-size half-filled grid (the cfg-3 `down`
     GEMM, all 256 CUs in the exchange at once), repeated calls on one workspace (the launcher re-zeroes the flags): == the oracle and == the default dispatch."""
@@ -261,6 +261,7 @@ def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
     bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if bias else None
     args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(),
             to_gpu(bv, code) if bias else None, TD[code])
+    pq_opt("PQ_FSK", "0")
     y_def = pq.qlinear_s8(*args)
     if M * N <= 1 << 20:
         acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)

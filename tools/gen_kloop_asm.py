@@ -361,16 +361,21 @@ def gen_variant(vid):
 #     at ((w * 32 + g) * 64 + lane) * 16) with WRITE-THROUGH (sc1) stores, wait for their acknowledgements, barrier, atomic_add(ready, 1), END THE WAVE;
 #   the last: poll ready (sc1 load) until it reaches nsl, then per slab 23 agent-scope (sc1) loads in flight into the dead fragment registers and 4
 #     v_add_u32 per group.  (A first version used hipcc's fence sequences — buffer_wbl2 sc1 / buffer_inv sc1 in every wave — and lost 35 us per launch to them.)
-FSK_ACC0, FSK_TMP0, FSK_NTMP = 128, 32, 23
-FSK_T = ("v124", "v125", "v126")        # 32-bit temporaries (the 24th fragment quad)
+# The pinned registers are the ones hipcc itself gives these operands in the product kernel (bf16 instantiation, ROCm 7.2: read off its disassembly) — with
+# that assignment the register allocation of the HIP-coded prologue and K-tile 0 has the solution it finds for the product kernel; an arbitrary block of
+# registers (v[128:255]) made it spill there.  First register of accumulator group g (order a, b, i, j) / of fragment quad q (order fPa, fPb, fQa, fQb):
+FSK_ACC_REG = [82, 50, 86, 54, 90, 58, 94, 62, 66, 14, 70, 10, 74, 6, 78, 2, 110, 98, 118, 102, 122, 106, 126, 114, 46, 30, 42, 26, 38, 232, 34, 18]
+FSK_TMP_REG = [200, 236, 204, 240, 208, 244, 216, 248, 146, 162, 150, 166, 154, 170, 158, 174, 212, 224, 220, 228, 130, 138, 134, 142]
+FSK_NTMP = 23
+FSK_T = tuple(f"v{FSK_TMP_REG[23] + k}" for k in range(3))        # 32-bit temporaries (the 24th fragment quad)
 
 
 def gen_fsk_tail(E):
     def R(text, size=4):
         E.raw(text, size, "fsk")
     t0, t1, t2 = FSK_T
-    accq = lambda g: f"v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]"
-    tmpq = lambda q: f"v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]"
+    accq = lambda g: f"v[{FSK_ACC_REG[g]}:{FSK_ACC_REG[g] + 3}]"
+    tmpq = lambda q: f"v[{FSK_TMP_REG[q]}:{FSK_TMP_REG[q] + 3}]"
     off = lambda g: (f" offset:{(g % 4) * 1024}" if g % 4 else "")
     R(f"v_mbcnt_lo_u32_b32 {t0}, -1, 0", 8)
     R(f"v_mbcnt_hi_u32_b32 {t0}, -1, {t0}", 8)
@@ -452,7 +457,7 @@ def gen_fsk_tail(E):
         R(f"s_waitcnt vmcnt({issued - 1 - j})")
         q = j % FSK_NTMP
         for r in range(4):
-            R(f"v_add_u32 v{FSK_ACC0 + 4 * j + r}, v{FSK_ACC0 + 4 * j + r}, v{FSK_TMP0 + 4 * q + r}")
+            R(f"v_add_u32 v{FSK_ACC_REG[j] + r}, v{FSK_ACC_REG[j] + r}, v{FSK_TMP_REG[q] + r}")
         if j + FSK_NTMP < 32:
             load(j + FSK_NTMP)
     R("s_add_u32 %[st1], %[st1], 1")
@@ -468,8 +473,8 @@ def gen_fsk_pair_tail(E):
     def R(text, size=4):
         E.raw(text, size, "fsk")
     t0, t1, t2 = FSK_T
-    accq = lambda g: f"v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]"
-    tmpq = lambda q: f"v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]"
+    accq = lambda g: f"v[{FSK_ACC_REG[g]}:{FSK_ACC_REG[g] + 3}]"
+    tmpq = lambda q: f"v[{FSK_TMP_REG[q]}:{FSK_TMP_REG[q] + 3}]"
     off = lambda k: (f" offset:{(k % 4) * 1024}" if k % 4 else "")
     R(f"v_mbcnt_lo_u32_b32 {t0}, -1, 0", 8)
     R(f"v_mbcnt_hi_u32_b32 {t0}, -1, {t0}", 8)
@@ -516,7 +521,7 @@ def gen_fsk_pair_tail(E):
         for k in range(16):
             R(f"s_waitcnt vmcnt({15 - k})")
             for r in range(4):
-                R(f"v_add_u32 v{FSK_ACC0 + 4 * (keep0 + k) + r}, v{FSK_ACC0 + 4 * (keep0 + k) + r}, v{FSK_TMP0 + 4 * k + r}")
+                R(f"v_add_u32 v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_TMP_REG[k] + r}")
         if sl == 0:
             R("s_branch L_fskp_end_%=")
     E.label("L_fskp_end_%=")
@@ -529,7 +534,7 @@ def c_operands(pinacc=False):
         for b in range(2):
             for i in range(4):
                 for j in range(2):
-                    con = f"+{{v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]}}" if pinacc else "+v"
+                    con = f"+{{v[{FSK_ACC_REG[g]}:{FSK_ACC_REG[g] + 3}]}}" if pinacc else "+v"
                     outs.append(f'[{acc(a, b, i, j)}] "{con}"(acc[{a}][{b}][{i}][{j}])')
                     g += 1
     for name, var, n in (("pa", "fPa", 4), ("pb", "fPb", 4), ("qa", "fQa", 2), ("qb", "fQb", 2)):
@@ -568,10 +573,10 @@ def _render_tail(name, doc, gen, args, ins):
         for b in range(2):
             for i in range(4):
                 for j in range(2):
-                    outs.append(f'"+{{v[{FSK_ACC0 + 4 * g}:{FSK_ACC0 + 4 * g + 3}]}}"(acc[{a}][{b}][{i}][{j}])')
+                    outs.append(f'"+{{v[{FSK_ACC_REG[g]}:{FSK_ACC_REG[g] + 3}]}}"(acc[{a}][{b}][{i}][{j}])')
                     g += 1
     for q in range(FSK_NTMP + 1):
-        outs.append(f'"=&{{v[{FSK_TMP0 + 4 * q}:{FSK_TMP0 + 4 * q + 3}]}}"(tmp[{q}])')
+        outs.append(f'"=&{{v[{FSK_TMP_REG[q]}:{FSK_TMP_REG[q] + 3}]}}"(tmp[{q}])')
     outs += ['[st0] "=&s"(fsk_st0)', '[st1] "=&s"(fsk_st1)', '[sx] "=&s"(fsk_sx)']
     out.append("        : " + ",\n          ".join(outs))
     out.append("        : " + ",\n          ".join(ins))
@@ -584,7 +589,7 @@ def _render_tail(name, doc, gen, args, ins):
 def render_fsk_tail():
     """the fused split-K hand-overs as statements of their own behind the K-loop statement (gemm_s8_sp256<..., FSK>)"""
     doc = ["// fsk_tail_asm: the hand-over of fused split-K, any number of slices (see gen_fsk_tail in tools/gen_kloop_asm.py).  Accumulator group g is",
-           f"// pinned to v[{FSK_ACC0}+4g : {FSK_ACC0 + 3}+4g], the {FSK_NTMP + 1} quads v[{FSK_TMP0}:{FSK_TMP0 + 4 * (FSK_NTMP + 1) - 1}] are the statement's temporaries.  A workgroup that is not the last of",
+           f"// pinned (FSK_ACC_REG in the generator), the {FSK_NTMP + 1} fragment quads (FSK_TMP_REG) are the statement's temporaries.  A workgroup that is not the last of",
            "// its tile to arrive ENDS inside the statement."]
     a = _render_tail("fsk_tail_asm", doc, gen_fsk_tail,
                      "const void* fsk_tick, const void* fsk_ready, const void* fsk_slab,\n        uint32_t fsk_nsl, uint32_t fsk_lds, uint32_t fsk_wave",
