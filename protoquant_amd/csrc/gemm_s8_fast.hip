@@ -79,7 +79,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // fused split-K workspace: bytes of the two per-tile counter arrays in front of the slabs
-__host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles) { return ((size_t)ntiles * 8 + 255) & ~(size_t)255; }
+__host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles, int kslices) { return ((size_t)ntiles * 4 * (kslices == 4 ? 4 : 2) + 255) & ~(size_t)255; }   // ticket form: {ticket, ready} per tile; symmetric forms: one flag per slice
 
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -120,9 +120,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // asm statement behind the K-loop's (fsk_tail_asm, registers pinned: tools/gen_kloop_asm.py gen_fsk_tail).  No second
 // pass over int32 slabs of the whole output, and half (or a quarter) of the slab traffic of the two-pass form.  `stamps` carries the
 // workspace: [tickets: ntiles u32][ready: ntiles u32] (zeroed by the launcher), padded to 256 B, then the slabs.
-// FSK = 2: the two-slice form, a SYMMETRIC exchange — workgroups 2 p and 2 p + 1 share tile p; each stores one column half of its partial sums,
-// waits for the partner's flag, adds the partner's half to the one it kept and runs the epilogue of that half (fsk_pair_asm): half the slab traffic
-// per CU, no idle CU, half an epilogue each.  (The wait is for a workgroup with the neighbouring id, dispatched with this one.)
+// FSK = 2 / 4: the two- / four-slice SYMMETRIC exchange — workgroups S p .. S p + S - 1 share tile p; each keeps one part of the accumulators (S = 2: a column
+// half of every wave block; S = 4: a quarter = column half x row half), stores the other parts, waits for the partners' flags, adds their contributions to the
+// part it kept and runs the epilogue of that part (fsk_sym2_asm / fsk_sym4_asm): no idle CU, 1 / S of an epilogue each.  (The wait is for workgroups with
+// neighbouring ids, dispatched together with this one.)
 template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4, int FSK = 0>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 : 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
@@ -178,12 +179,13 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     // split-K (int32 output only): blocks [s*ntiles, (s+1)*ntiles) own K-slice s and write their exact partial
     // accumulators to slab s of the output buffer; a separate kernel sums the slabs and applies the epilogue.
     const int ntiles_all = tiles_m * tiles_n;
-    const int kslice = FSK == 2 ? ((int)blockIdx.x & 1) : (int)blockIdx.x / ntiles_all;
+    const int kslice = FSK >= 2 ? ((int)blockIdx.x & (FSK - 1)) : (int)blockIdx.x / ntiles_all;
     const int Ks = K / kslices;                       // bytes of K per slice (a multiple of FBK)
     int t;
-    if constexpr (FSK == 2) {      // partners 2 p, 2 p + 1 (neighbouring XCDs); pairs p, p + 4, p + 8 ... share the two XCDs: a contiguous run of tiles for them
-        const int p = (int)blockIdx.x >> 1, q4 = ntiles_all >> 2, r4 = ntiles_all & 3, grp = p & 3, idx = p >> 2;
-        t = (grp < r4 ? grp * (q4 + 1) : r4 * (q4 + 1) + (grp - r4) * q4) + idx;
+    if constexpr (FSK >= 2) {      // partners S p .. S p + S - 1 (neighbouring XCDs); every (8 / S)-th partner set shares those XCDs: a contiguous run of tiles for them
+        constexpr int NGX = 8 / FSK;
+        const int p = (int)blockIdx.x / FSK, qg = ntiles_all / NGX, rg = ntiles_all % NGX, grp = p % NGX, idx = p / NGX;
+        t = (grp < rg ? grp * (qg + 1) : rg * (qg + 1) + (grp - rg) * qg) + idx;
     } else {
         t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all);
     }
@@ -514,14 +516,14 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             if constexpr (FSK == 1) {
                 // the hand-over: the first kslices - 1 workgroups of a tile to arrive END inside this statement, the last leaves it with the tile's sums
                 unsigned* const ctr = reinterpret_cast<unsigned*>(stamps);
-                const uint8_t* const slab0 = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all) + (size_t)t * (size_t)(kslices - 1) * (256 * 256 * 4);
+                const uint8_t* const slab0 = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all, kslices) + (size_t)t * (size_t)(kslices - 1) * (256 * 256 * 4);
                 fsk_tail_asm(acc, ctr + t, ctr + ntiles_all + t, slab0, (uint32_t)(kslices - 1), smem_base + (uint32_t)scale_off + 2048u, (uint32_t)wave);
-            } else if constexpr (FSK == 2) {
-                // the exchange: this workgroup leaves the statement with the tile's sums in accumulator half a = kslice
-                unsigned* const flags = reinterpret_cast<unsigned*>(stamps) + 2 * t;
-                const uint8_t* const slabs = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all) + (size_t)t * (256 * 256 * 4);
-                fsk_pair_asm(acc, flags + kslice, flags + (kslice ^ 1), slabs + (size_t)kslice * (128 * 256 * 4), slabs + (size_t)(kslice ^ 1) * (128 * 256 * 4),
-                             (uint32_t)wave, (uint32_t)kslice);
+            } else if constexpr (FSK >= 2) {
+                // the exchange: this workgroup leaves the statement with the tile's sums in accumulator part `kslice`
+                const unsigned* const flags = reinterpret_cast<const unsigned*>(stamps) + FSK * t;
+                const uint8_t* const slabs = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all, FSK) + (size_t)t * (size_t)(FSK - 1) * (256 * 256 * 4);
+                if constexpr (FSK == 2) fsk_sym2_asm(acc, flags, slabs, (uint32_t)wave, (uint32_t)kslice);
+                else fsk_sym4_asm(acc, flags, slabs, (uint32_t)wave, (uint32_t)kslice);
             }
         }
     } else {
@@ -566,10 +568,12 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     constexpr int NG = 1;
 
-    // (HALF = -1: the whole wave block; 0 / 1: one column half of it — the two-slice fused split-K finishes acc[HALF][..] only)
-    auto epilogue = [&](auto half_c) {
-        constexpr int HALF = decltype(half_c)::value;
-        constexpr int COL0 = HALF < 0 ? 0 : HALF * PWH;             // first column of the half inside the wave block
+    // (HALF = -1: all columns of the wave block; 0 / 1: one column half of it; HALFQ likewise for its rows — the symmetric fused split-K forms finish
+    // acc[HALF][..] (two slices) or acc[HALF][HALFQ][..] (four) only)
+    auto epilogue = [&](auto half_c, auto halfq_c) {
+        constexpr int HALF = decltype(half_c)::value, HALFQ = decltype(halfq_c)::value;
+        constexpr int COL0 = HALF < 0 ? 0 : HALF * PWH;             // first column / row of the part inside the wave block
+        constexpr int ROW0 = HALFQ < 0 ? 0 : HALFQ * QW;
         // staged path: whole block in range, 16-byte aligned rows
         const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
                             ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
@@ -584,16 +588,16 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             const int last_slot = (NT - 1) % NBUF;
             const uint32_t sw_off = P3 ? (uint32_t)((w < 4 ? p_off((NT + 1) % 3) : q_off(NT % 2)) + (w & 3) * WREG)
                                        : (uint32_t)((last_slot + 1 == NBUF ? 0 : last_slot + 1) * BUFB + w * WREG);
-            constexpr int NPT = (HALF < 0 ? 2 : 1) * NPI, NQT = 2 * NQJ;        // column / row tiles of the wave block (HALF >= 0: of its column half)
+            constexpr int NPT = (HALF < 0 ? 2 : 1) * NPI, NQT = (HALFQ < 0 ? 2 : 1) * NQJ;   // column / row tiles of the wave block (of the part)
             constexpr int PT_PASS = (NPT * 16 * OB > 256) ? NPT / 2 : NPT;      // staged rows of at most 256 bytes
             constexpr int QT_PASS_MAX = WREG / (16 * PT_PASS * 16 * OB);
             constexpr int QT_PASS = QT_PASS_MAX >= NQT ? NQT : (QT_PASS_MAX >= 2 ? 2 : 1);
             static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= WREG, "epilogue staging region");
-            auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[HALF < 0 ? pt / NPI : HALF][qt / NQJ][pt % NPI][qt % NQJ]; };
-            auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + qt * 16 + dcol]; };
+            auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[HALF < 0 ? pt / NPI : HALF][HALFQ < 0 ? qt / NQJ : HALFQ][pt % NPI][qt % NQJ]; };
+            auto as_of = [&](int qt) { return reinterpret_cast<const float*>(smem + scale_off)[wq * WM + ROW0 + qt * 16 + dcol]; };
             auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(smem + scale_off + 1024 + (wp * WN + COL0 + pt * 16 + drow4) * 4); };
-            uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)wm0 * epi.ldy + wn0 + COL0);
-            const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 : wn0 + COL0)) : nullptr;
+            uint8_t* y_blk = reinterpret_cast<uint8_t*>(y + (int64_t)(wm0 + ROW0) * epi.ldy + wn0 + COL0);
+            const void* bias_blk = has_bias ? static_cast<const void*>(reinterpret_cast<const O*>(epi.bias) + ((epi.flags & EPI_BIAS_ROWS) ? wm0 + ROW0 : wn0 + COL0)) : nullptr;
             PQ_EPI_STAGED_DISPATCH(OUT, NPT, NQT, QT_PASS, PT_PASS, has_bias, epi.flags, acc_of, as_of, bs_of, bias_blk, smem, sw_off, y_blk, epi.ldy * OB, lane_e);
             stamp(3);
             return;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
         // direct path (edge tiles / unaligned y): guarded stores straight from registers
         const bool vec_ok = ((reinterpret_cast<uintptr_t>(y) & (4 * OB - 1)) == 0) && ((epi.ldy & 3) == 0);
 #pragma unroll
-        for (int hQ = 0; hQ < 2; ++hQ)
+        for (int hQ = (HALFQ < 0 ? 0 : HALFQ); hQ < (HALFQ < 0 ? 2 : HALFQ + 1); ++hQ)
 #pragma unroll
             for (int j = 0; j < NQJ; ++j) {
                 const int m = wm0 + hQ * QW + j * SHAPE + dcol;
@@ -647,11 +651,19 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
                         }
             }
     };
+    constexpr std::integral_constant<int, -1> all{};
+    constexpr std::integral_constant<int, 0> h0{};
+    constexpr std::integral_constant<int, 1> h1{};
     if constexpr (FSK == 2) {
-        if (kslice == 0) epilogue(std::integral_constant<int, 0>{});
-        else epilogue(std::integral_constant<int, 1>{});
+        if (kslice == 0) epilogue(h0, all);
+        else epilogue(h1, all);
+    } else if constexpr (FSK == 4) {
+        if (kslice == 0) epilogue(h0, h0);
+        else if (kslice == 1) epilogue(h0, h1);
+        else if (kslice == 2) epilogue(h1, h0);
+        else epilogue(h1, h1);
     } else {
-        epilogue(std::integral_constant<int, -1>{});
+        epilogue(all, all);
     }
 }
 
@@ -979,20 +991,25 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
 }
 
 // ---- fused split-K (gemm_s8_sp256<..., FSK>): kslices workgroups per 256 x 256 tile, partial sums handed over inside the kernel
+bool g_fsk_sym4 = true;     // four slices: the symmetric exchange (pq_set_option("PQ_FSK_TICKET", "1") takes the ticket form instead: A/B runs)
+void set_fsk_sym4(bool v) { g_fsk_sym4 = v; }
 size_t fsk_workspace_bytes(int64_t M, int64_t N, int kslices) {
     const int64_t ntiles = ((M + 255) / 256) * ((N + 255) / 256);
-    return fsk_counter_bytes((int)ntiles) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
+    return fsk_counter_bytes((int)ntiles, kslices) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
 }
 template <int OUT>
 void launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
                      int kslices, void* workspace, hipStream_t st) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    (void)hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n), st);        // tickets and ready counts
+    (void)hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st);        // tickets and ready counts / flags
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
+    unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
     if (kslices == 2)
-        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, static_cast<unsigned long long*>(workspace), 2);
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 2);
+    else if (kslices == 4 && g_fsk_sym4)
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 4);
     else
-        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, static_cast<unsigned long long*>(workspace), kslices);
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, kslices);
 }
 template void launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 template void launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);

@@ -24,6 +24,7 @@ template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 template <int OUT> void launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 size_t fsk_workspace_bytes(int64_t, int64_t, int);
+void set_fsk_sym4(bool);
 void set_stamp_buffer(unsigned long long*);
 void set_skinny_rb(int);
 void set_k1_rpw(int);
@@ -88,7 +89,7 @@ struct Options {
 Options g_opt;
 std::once_flag g_opt_once;
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_TICKET", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(const char* name, const char* value) {
     if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
@@ -96,6 +97,7 @@ bool apply_option(const char* name, const char* value) {
     else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
     else if (!strcmp(name, "PQ_FORCE_SPLITK")) g_opt.force_splitk = value && *value ? atoi(value) : 0;
     else if (!strcmp(name, "PQ_FSK")) g_opt.fsk = value && *value ? atoi(value) : -1;
+    else if (!strcmp(name, "PQ_FSK_TICKET")) pq::set_fsk_sym4(!(value && *value == '1'));
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
     else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
     else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
@@ -372,13 +374,17 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
 // grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008): two workgroups per tile, symmetric exchange.  Measured against the 128 x 256 tile
 // (profiles/r03_ab_fsk.txt, run 5): weights from HBM — what a layer inside a model sees — 73.5 against 84.1 us (K = 14336: 90.7 against 98.8; 16384: 101.4
 // against 105.7); weights warm 71.8 against 68.4 us (88.4 / 87.4, 99.1 / 99.4).  PQ_FSK=0 turns it off, PQ_FSK=S (experiments) forces S slices wherever the
-// shape admits them (S > 2: the ticket form, which ties with the two-pass split-K on the 70B `down` shard and is not chosen by the plan).
+// shape admits them (S = 2 / 4: the symmetric exchanges; other S, or PQ_FSK_TICKET=1: the ticket form).
 static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     const int f = options().fsk;
     if (f == 0 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
     if (f > 1) return (K % (128 * f) == 0 && K / f >= 5 * 128) ? f : 0;
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    return (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) ? 2 : 0;
+    if (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) return 2;
+    // the quarter-filled grid with a very long K (the Llama-70B `down` shard, 4096 x 1024 x 28672): four slices, four-way symmetric exchange — 91.3 / 92.1 us
+    // (warm / HBM-fed) against 98.9 / 99.3 for the two-pass split-K and 99 / 128 for the ring tile; at K = 16384 the ring tile still wins (r03_ab_fsk.txt, run 6)
+    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) return 4;
+    return 0;
 }
 
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {

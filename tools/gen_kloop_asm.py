@@ -465,66 +465,92 @@ def gen_fsk_tail(E):
     R("s_cbranch_scc1 L_fsk_slab_%=")
 
 
-# ---- the two-slice form: a SYMMETRIC exchange.  Workgroup s of the pair keeps accumulator half a = s (groups 16 s .. 16 s + 15: the output columns
-# hP = s of every wave block), stores the other half to its own slab (128 KiB, write-through), raises its flag, waits for the partner's flag, adds the
-# partner's half-slab to the half it keeps and runs the epilogue of that half: half the slab traffic per CU, both CUs busy, half an epilogue each.
-# The wait is for a workgroup that may not have started yet: the launcher numbers the partners 2 p and 2 p + 1, so that they are dispatched together.
-def gen_fsk_pair_tail(E):
+# ---- the SYMMETRIC exchange (S = 2 or 4 slices).  Workgroup s of a tile's S keeps accumulator part s — groups (32 / S) s .. : for S = 2 the column half a = s of
+# every wave block, for S = 4 the quarter (column half a = s >> 1, row half b = s & 1) — stores the other parts to its own slab regions (write-through), raises
+# its flag, waits for the partners' flags, adds their contributions to the part it keeps and runs the epilogue of that part: 1 / S of the slab traffic of the
+# ticket form on the critical path, no idle CU, 1 / S of an epilogue each.  The wait is for workgroups that may not have started yet: the launcher numbers the
+# partners S p .. S p + S - 1, so that they are dispatched together.  Slab region of (writer s, destination d): index s (S - 1) + (d < s ? d : d - 1), 256 / S KiB
+# each, inside it group k of wave w at ((w * 32 / S + k) * 64 + lane) * 16.
+def gen_fsk_sym_tail(E, S):
     def R(text, size=4):
         E.raw(text, size, "fsk")
     t0, t1, t2 = FSK_T
+    GP = 32 // S                                  # groups per part
+    REG = GP * 8 * 1024                           # bytes of one region
     accq = lambda g: f"v[{FSK_ACC_REG[g]}:{FSK_ACC_REG[g] + 3}]"
     tmpq = lambda q: f"v[{FSK_TMP_REG[q]}:{FSK_TMP_REG[q] + 3}]"
     off = lambda k: (f" offset:{(k % 4) * 1024}" if k % 4 else "")
+    region = lambda w, d: w * (S - 1) + (d if d < w else d - 1)
+    tag = f"y{S}"
     R(f"v_mbcnt_lo_u32_b32 {t0}, -1, 0", 8)
     R(f"v_mbcnt_hi_u32_b32 {t0}, -1, {t0}", 8)
     R(f"v_lshlrev_b32 {t0}, 4, {t0}")
-    R("s_lshl_b32 %[st0], %[wv], 14")
-    R(f"v_add_u32 {t0}, %[st0], {t0}")                       # t0 = wave * 16 KiB + lane * 16
-    R("s_cmp_lg_u32 %[sl], 0")
-    R("s_cbranch_scc1 L_fskp_s1_%=")
-    for sl in (0, 1):
-        keep0, send0 = 16 * sl, 16 * (1 - sl)
+    R(f"s_mul_i32 %[st0], %[wv], {GP * 1024}")
+    R(f"v_add_u32 {t0}, %[st0], {t0}")                       # t0 = wave * (32 / S) KiB + lane * 16
+    for sl in range(1, S):
+        R(f"s_cmp_eq_u32 %[sl], {sl}")
+        R(f"s_cbranch_scc1 L_fsk{tag}_s{sl}_%=")
+    for sl in range(S):
+        keep0 = GP * sl
         if sl:
-            E.label("L_fskp_s1_%=")
-        R(f"v_mov_b32 {t1}, {t0}")
-        for k in range(16):
-            if k and k % 4 == 0:
-                R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
-            R(f"global_store_dwordx4 {t1}, {accq(send0 + k)}, %[mslab]" + off(k) + " sc1", 8)
+            E.label(f"L_fsk{tag}_s{sl}_%=")
+        for d in range(S):
+            if d == sl:
+                continue
+            R(f"v_add_u32 {t1}, 0x{region(sl, d) * REG:x}, {t0}", 8)
+            for k in range(GP):
+                if k and k % 4 == 0:
+                    R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
+                R(f"global_store_dwordx4 {t1}, {accq(GP * d + k)}, %[slab]" + off(k) + " sc1", 8)
         R("s_waitcnt vmcnt(0)")
         R("s_barrier")
         R("s_cmp_lg_u32 %[wv], 0")
-        R(f"s_cbranch_scc1 L_fskp_w{sl}_%=")
+        R(f"s_cbranch_scc1 L_fsk{tag}_w{sl}_%=")
         R("s_mov_b64 %[sx], exec")
         R("s_mov_b64 exec, 1")
         R(f"v_mov_b32 {t1}, 1")
-        R(f"v_mov_b32 {t2}, 0")
-        R(f"global_atomic_add {t2}, {t1}, %[mflag]", 8)
-        E.label(f"L_fskp_poll{sl}_%=")
-        R(f"global_load_dword {t1}, {t2}, %[pflag] sc1", 8)
-        R("s_waitcnt vmcnt(0)")
-        R(f"v_readfirstlane_b32 %[st1], {t1}")
-        R("s_cmp_ge_u32 %[st1], 1")
-        R(f"s_cbranch_scc1 L_fskp_pd{sl}_%=")
-        R("s_sleep 4")
-        R(f"s_branch L_fskp_poll{sl}_%=")
-        E.label(f"L_fskp_pd{sl}_%=")
+        R(f"v_mov_b32 {t2}, {4 * sl}")
+        R(f"global_atomic_add {t2}, {t1}, %[flags]", 8)
+        for d in range(S):
+            if d == sl:
+                continue
+            R(f"v_mov_b32 {t2}, {4 * d}")
+            E.label(f"L_fsk{tag}_poll{sl}{d}_%=")
+            R(f"global_load_dword {t1}, {t2}, %[flags] sc1", 8)
+            R("s_waitcnt vmcnt(0)")
+            R(f"v_readfirstlane_b32 %[st1], {t1}")
+            R("s_cmp_ge_u32 %[st1], 1")
+            R(f"s_cbranch_scc1 L_fsk{tag}_pd{sl}{d}_%=")
+            R("s_sleep 4")
+            R(f"s_branch L_fsk{tag}_poll{sl}{d}_%=")
+            E.label(f"L_fsk{tag}_pd{sl}{d}_%=")
         R("s_mov_b64 exec, %[sx]")
-        E.label(f"L_fskp_w{sl}_%=")
+        E.label(f"L_fsk{tag}_w{sl}_%=")
         R("s_barrier")
-        R(f"v_mov_b32 {t1}, {t0}")
-        for k in range(16):
-            if k and k % 4 == 0:
+        items = [(d, k) for d in range(S) if d != sl for k in range(GP)]       # contributions to group keep0 + k, in load order
+        issued = 0
+
+        def load(n):
+            nonlocal issued
+            d, k = items[n]
+            if k == 0:
+                R(f"v_add_u32 {t1}, 0x{region(d, sl) * REG:x}, {t0}", 8)
+            elif k % 4 == 0:
                 R(f"v_add_u32 {t1}, 0x1000, {t1}", 8)
-            R(f"global_load_dwordx4 {tmpq(k)}, {t1}, %[pslab]" + off(k) + " sc1", 8)
-        for k in range(16):
-            R(f"s_waitcnt vmcnt({15 - k})")
+            R(f"global_load_dwordx4 {tmpq(n % FSK_NTMP)}, {t1}, %[slab]" + off(k) + " sc1", 8)
+            issued += 1
+        for n in range(min(FSK_NTMP, len(items))):
+            load(n)
+        for n, (d, k) in enumerate(items):
+            R(f"s_waitcnt vmcnt({issued - 1 - n})")
+            q = n % FSK_NTMP
             for r in range(4):
-                R(f"v_add_u32 v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_TMP_REG[k] + r}")
-        if sl == 0:
-            R("s_branch L_fskp_end_%=")
-    E.label("L_fskp_end_%=")
+                R(f"v_add_u32 v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_ACC_REG[keep0 + k] + r}, v{FSK_TMP_REG[q] + r}")
+            if n + FSK_NTMP < len(items):
+                load(n + FSK_NTMP)
+        if sl < S - 1:
+            R(f"s_branch L_fsk{tag}_end_%=")
+    E.label(f"L_fsk{tag}_end_%=")
 
 
 def c_operands(pinacc=False):
@@ -594,12 +620,14 @@ def render_fsk_tail():
     a = _render_tail("fsk_tail_asm", doc, gen_fsk_tail,
                      "const void* fsk_tick, const void* fsk_ready, const void* fsk_slab,\n        uint32_t fsk_nsl, uint32_t fsk_lds, uint32_t fsk_wave",
                      ['[tick] "s"(fsk_tick)', '[rdy] "s"(fsk_ready)', '[slab] "s"(fsk_slab)', '[nsl] "s"(fsk_nsl)', '[tkl] "s"(fsk_lds)', '[wv] "s"(fsk_wave)'])
-    doc = ["// fsk_pair_asm: the symmetric exchange of the two-slice form (gen_fsk_pair_tail): slice s leaves the statement with the tile's sums in",
-           "// accumulator half a = s (groups 16 s .. 16 s + 15); the other half is dead."]
-    b = _render_tail("fsk_pair_asm", doc, gen_fsk_pair_tail,
-                     "const void* my_flag, const void* peer_flag, const void* my_slab, const void* peer_slab,\n        uint32_t fsk_wave, uint32_t fsk_slice",
-                     ['[mflag] "s"(my_flag)', '[pflag] "s"(peer_flag)', '[mslab] "s"(my_slab)', '[pslab] "s"(peer_slab)', '[wv] "s"(fsk_wave)', '[sl] "s"(fsk_slice)'])
-    return a + b
+    out = a
+    for S in (2, 4):
+        doc = [f"// fsk_sym{S}_asm: the symmetric exchange of the {S}-slice form (gen_fsk_sym_tail): slice s leaves the statement with the tile's sums in",
+               f"// accumulator part s (groups {32 // S} s .. {32 // S} s + {32 // S - 1}); the other parts are dead."]
+        out += _render_tail(f"fsk_sym{S}_asm", doc, lambda E, S=S: gen_fsk_sym_tail(E, S),
+                            "const void* tile_flags, const void* tile_slab, uint32_t fsk_wave, uint32_t fsk_slice",
+                            ['[flags] "s"(tile_flags)', '[slab] "s"(tile_slab)', '[wv] "s"(fsk_wave)', '[sl] "s"(fsk_slice)'])
+    return out
 
 
 PRODUCT = (1, 2, 3, 4)         # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
