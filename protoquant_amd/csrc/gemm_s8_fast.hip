@@ -997,11 +997,12 @@ size_t fsk_workspace_bytes(int64_t M, int64_t N, int kslices) {
     const int64_t ntiles = ((M + 255) / 256) * ((N + 255) / 256);
     return fsk_counter_bytes((int)ntiles, kslices) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
 }
+// (returns false, WITHOUT launching, when the flags could not be zeroed: the kernel's waits would never end on flags that hold garbage)
 template <int OUT>
-void launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
+bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
                      int kslices, void* workspace, hipStream_t st) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    (void)hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st);        // tickets and ready counts / flags
+    if (hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st) != hipSuccess) return false;   // tickets and ready counts / flags
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
     if (kslices == 2)
@@ -1010,10 +1011,11 @@ void launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 4);
     else
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, kslices);
+    return true;
 }
-template void launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
-template void launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
-template void launch_gemm_fsk<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template bool launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template bool launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template bool launch_gemm_fsk<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 
 // ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
 // the slabs (exact) and applies QSPEC E1-E4.  Doubles/quadruples the busy CUs for small-MN / long-K problems.

@@ -22,7 +22,7 @@ template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
-template <int OUT> void launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template <int OUT> bool launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 size_t fsk_workspace_bytes(int64_t, int64_t, int);
 void set_fsk_sym4(bool);
 void set_stamp_buffer(unsigned long long*);
@@ -407,11 +407,13 @@ static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, cons
         if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);
         if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "%s: workspace must be 16-byte aligned", what);
         if (!pq::epi_flags_valid(epi.flags, epi.bias != nullptr)) abort();
+        bool launched;
         switch (out_dtype) {
-            case PQ_BF16: pq::launch_gemm_fsk<PQ_BF16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
-            case PQ_FP16: pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
-            default: pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+            case PQ_BF16: launched = pq::launch_gemm_fsk<PQ_BF16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+            case PQ_FP16: launched = pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
+            default: launched = pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
         }
+        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "%s: the split-K workspace could not be initialised (hipMemsetAsync failed)", what); }
         return check_launch(what);
     }
     int tm = 256;
