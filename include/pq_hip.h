@@ -94,8 +94,11 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
  *   y[m,n] = cast_rne_out((f32(acc[m,n]) * a_scale[m]) * b_scale[n] (+ f32(bias[n])))   QSPEC E1-E4.
  * bias is nullable and has the output dtype.
  * workspace: optional.  pq_qlinear_workspace_bytes(M,N,K) > 0 marks problems (small M*N, long K) for which a
- * 16-byte aligned device workspace of that size enables split-K (partial int32 slabs + an exact integer reduction:
- * results are bit-identical); with workspace == NULL the single-pass kernel runs instead. */
+ * 16-byte aligned device workspace of that size enables split-K — partial int32 sums either in slabs of the whole
+ * output + an exact integer reduction pass, or handed over between the workgroups of a tile inside the GEMM kernel
+ * (flags + per-tile slabs; the call re-initialises the flags itself): results are bit-identical.  The contents need
+ * not be initialised or preserved; one workspace must not serve two calls that may run concurrently.  With
+ * workspace == NULL the single-pass kernel runs instead. */
 int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       const int8_t* b, int64_t ldb, const float* b_scale,
                       const void* bias, void* y, int64_t ldy, int32_t out_dtype,
@@ -140,7 +143,7 @@ int32_t pq_selftest_half_encode(int32_t dtype, unsigned long long* counts, void*
 int32_t pq_selftest_silu_short(int32_t dtype, unsigned long long* counts, void* stream);
 
 /* Name of the single-pass GEMM kernel variant the dispatcher would pick for this problem (static string); with a workspace
- * (pq_qlinear_workspace_bytes > 0) pq_qlinear_s8 runs split-K slices + a reduction pass instead. */
+ * (pq_qlinear_workspace_bytes > 0) pq_qlinear_s8 runs a split-K form of the 256 x 256 (or 128 x 256) tile instead. */
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 
 #ifdef __cplusplus
