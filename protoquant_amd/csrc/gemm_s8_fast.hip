@@ -963,7 +963,7 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     if constexpr (TM == 256 && TN == 256) {
         if (g_sp256_p3) {
             // K-tiles 1 .. NT-1 in the hand-allocated asm statement (kloop_p3_asm.inc, variant 1) whenever there are at least five K-tiles;
-            // PQ_SP256_ASM=0 keeps the HIP loop (same bits), 2 / 3 are the A/B and timing-only variants (bf16 output only)
+            // PQ_SP256_ASM=0 keeps the HIP loop (same bits); dev builds: 2 / 3 / 6-9 are the A/B and timing-only variants (bf16 output only)
             const int av = K >= 5 * FBK ? g_sp256_asm : 0;
             if (av == 1 && g_sp256_persist && tiles_m * tiles_n > 256) {       // more than one round: one workgroup per CU walks its tiles
                 launch_gemm_p3_persist<OUT>(A, lda, B, ldb, epi, M, N, K, st);
@@ -974,9 +974,9 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
                 return;
             }
             if constexpr (OUT == PQ_BF16) {
+#ifdef PQ_ABLATION_BUILD      // dev builds only: the A/B placement variant (2) and the timing-only variants, whose results are WRONG (3: no waits / barriers; 6-9: ablations)
                 if (av == 2) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
                 if (av == 3) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 3><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
-#ifdef PQ_ABLATION_BUILD      // timing-only ablations of the asm loop (dev builds)
                 if (av == 6) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 6><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
                 if (av == 7) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 7><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }
                 if (av == 8) { gemm_s8_sp256<OUT, 0, TM, TN, false, true, 8><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1); return; }

@@ -630,7 +630,7 @@ def render_fsk_tail():
     return out
 
 
-PRODUCT = (1, 2, 3, 4)         # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
+PRODUCT = (1, 4)               # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
 OUT_DEV = os.path.join(ROOT, "protoquant_amd", "csrc", "kloop_p3_asm_dev.inc")
 ARGS = ("v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],\n"
         "        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],\n"
