@@ -7,7 +7,8 @@ not of the reference itself — "parity unpinned" (oracle/README.md).  Fixtures 
 and expected outputs; half tensors are stored as uint16 bit patterns.
 
 Cases: ragged 5x7x3 and 17x16x8, BASELINE config-1 shape 32x512x512 (fp32 and
-bf16 inputs), one 256x384x512 bf16 with bias, an fp16 case, an outlier case, a zero-row case.
+bf16 inputs), one 256x384x512 bf16 with bias, an fp16 case, an outlier case, a zero-row case, and four
+special-value cases (NaN, +-Inf, signalling NaN, subnormals, -0.0, all-zero and all-NaN rows; NaN / Inf weight channels).
 """
 import os
 import sys
@@ -28,12 +29,40 @@ def bits(t: torch.Tensor) -> np.ndarray:
     return t.contiguous().numpy().copy()
 
 
-def make_case(name, M, N, K, dtype, seed, bias=False, outliers=False, zero_rows=False, wscale=0.02):
+def plant_specials(x: torch.Tensor, dtype: str):
+    """QSPEC v2 special values, planted into a random [M >= 12, K >= 8] matrix (rows named by what they hold):
+    1 one NaN · 2 one +Inf · 3 all zero · 4 -Inf and NaN · 5 all subnormal · 6 a signalling NaN · 7 all NaN ·
+    8 -0.0 and the largest finite value · 9 one subnormal among zeros · column 7 holds a NaN in row 10 only (so the
+    per-channel quantisation has NaN columns 3, 1, 2 (row 6's), 7 and all of row 7's)."""
+    td = TORCH_DT[dtype]
+    tiny = {"bf16": 1e-40, "fp16": 6e-8, "f32": 1e-41}[dtype]
+    big = {"bf16": 3.3895e38, "fp16": 65504.0, "f32": 3.4028234e38}[dtype]
+    x[1, 3] = float("nan")
+    x[2, 5] = float("inf")
+    x[3, :] = 0
+    x[4, 0] = float("-inf"); x[4, 1] = float("nan")
+    x[5, :] = tiny
+    x[7, :] = float("nan")
+    x[8, 0] = -0.0; x[8, 4] = big
+    x[9, :] = 0; x[9, 6] = tiny
+    x[10, 7] = float("nan")
+    if td is torch.float32:
+        x.view(torch.int32)[6, 2] = 0x7F800001                       # signalling NaN bit patterns
+    else:
+        x.view(torch.int16)[6, 2] = 0x7F81 if td is torch.bfloat16 else 0x7C01
+    return x
+
+
+def make_case(name, M, N, K, dtype, seed, bias=False, outliers=False, zero_rows=False, wscale=0.02, specials=False):
     g = torch.Generator().manual_seed(seed)
     td = TORCH_DT[dtype]
     x = torch.randn(M, K, generator=g).to(td)
     w = (torch.randn(N, K, generator=g) * wscale).to(td)
     b = (torch.randn(N, generator=g) * 0.01).to(td) if bias else None
+    if specials:
+        x = plant_specials(x, dtype)
+        w[N - 2, 1] = float("nan")                # a NaN weight channel: its scale is NaN, its output column NaN
+        w[N - 3, 0] = float("inf")
     if outliers:                                  # 1 % of the x columns x20 (SURVEY §8d)
         cols = torch.randperm(K, generator=g)[: max(1, K // 100)]
         x[:, cols] = (x[:, cols].float() * 20).to(td)
@@ -71,6 +100,12 @@ def main():
     make_case("mid_64x128x256_fp16_bias", 64, 128, 256, "fp16", 14, bias=True)
     make_case("outlier_48x80x200_bf16", 48, 80, 200, "bf16", 15, outliers=True)
     make_case("zerorow_33x65x129_bf16", 33, 65, 129, "bf16", 16, zero_rows=True, bias=True)
+    # QSPEC v2 NaN / Inf / sNaN / subnormal / all-zero policy, generated by the torch form (float outputs hold NaNs: tests
+    # compare those as a class, everything else bit for bit)
+    make_case("special_12x24x40_bf16", 12, 24, 40, "bf16", 21, bias=True, specials=True)
+    make_case("special_12x24x40_fp16", 12, 24, 40, "fp16", 22, specials=True)
+    make_case("special_13x9x37_f32", 13, 9, 37, "f32", 23, bias=True, specials=True)
+    make_case("special_16x128x256_bf16", 16, 128, 256, "bf16", 24, specials=True)     # vector-path widths
 
 
 if __name__ == "__main__":

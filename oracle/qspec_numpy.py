@@ -49,6 +49,9 @@ def from_f32(t: np.ndarray, dtype) -> np.ndarray:
 
 
 # ---------------------------------------------------------------- QSPEC stages
+_CANON_NAN = np.array([0x7FC00000], np.uint32).view(np.float32)[0]
+
+
 def quantize(x: np.ndarray, dtype, reduce_axis: int):
     """QSPEC Q1-Q6. reduce_axis = 1 (per-token rows) or 0 (per-channel columns)."""
     xf = to_f32(x, dtype)
@@ -58,10 +61,10 @@ def quantize(x: np.ndarray, dtype, reduce_axis: int):
         if xf.shape[reduce_axis] == 0:
             amax = np.zeros(xf.shape[1 - reduce_axis], np.float32)
         else:
-            amax = np.fmax.reduce(ax, axis=reduce_axis)        # NaN-ignoring max (Q2)
-            amax = np.where(np.isnan(amax), np.float32(0), amax).astype(np.float32)
+            amax = np.maximum.reduce(ax, axis=reduce_axis).astype(np.float32)   # Q2: NaN-PROPAGATING max (np.maximum, like torch.amax)
         scale = (amax / np.float32(127.0)).astype(np.float32)    # Q3 true division
         scale = np.where(amax == 0, np.float32(1.0), scale).astype(np.float32)
+        scale = np.where(np.isnan(scale), _CANON_NAN, scale).astype(np.float32)   # Q3: a NaN scale is the canonical quiet NaN 0x7FC00000
         s = np.expand_dims(scale, reduce_axis)
         t = np.rint((xf / s).astype(np.float32))                 # Q4 true division + RNE
         t = np.where(np.isnan(t), np.float32(0), t)              # Q5 NaN -> 0

@@ -66,10 +66,13 @@ static inline void store_f32(void* p, int dtype, int64_t i, float v) {
     }
 }
 
-/* QSPEC Q2: NaN-ignoring running max of |x| (a compare that is false for any NaN, quiet or signalling) */
-static inline float amax_step(float amax, float v) { float a = fabsf(v); return a > amax ? a : amax; }
-/* QSPEC Q3: scale = amax/127 (true division), 1.0 when amax == 0 */
-static inline float scale_of(float amax) { return amax == 0.0f ? 1.0f : amax / 127.0f; }
+/* QSPEC Q2: running max of |x| that PROPAGATES a NaN (as torch.amax does): once NaN, always NaN */
+static inline float amax_step(float amax, float v) { float a = fabsf(v); return (a > amax || a != a) ? a : amax; }
+/* QSPEC Q3: scale = amax/127 (true division), 1.0 when amax == 0; a NaN scale is the canonical quiet NaN 0x7FC00000 */
+static inline float scale_of(float amax) {
+    if (amax != amax) { const uint32_t u = 0x7FC00000u; float f; memcpy(&f, &u, 4); return f; }
+    return amax == 0.0f ? 1.0f : amax / 127.0f;
+}
 /* QSPEC Q4-Q6: q = clamp(rne(x/scale)), NaN -> 0 */
 static inline int8_t code_of(float x, float scale) {
     float t = rintf(x / scale);            /* default rounding mode: half-to-even */

@@ -21,15 +21,23 @@ QMAX = 127.0
 
 def quantize_ref(x: torch.Tensor, reduce_dim: int):
     """QSPEC quantize. ``reduce_dim`` is the axis the amax is taken over (-1/1: per-token rows,
-    0: per-channel columns of a row-major matrix).  Returns (int8 codes, fp32 scale vector)."""
+    0: per-channel columns of a row-major matrix).  Returns (int8 codes, fp32 scale vector).
+
+    NaN / Inf (QSPEC v2, Q2/Q3/Q5 — PROPAGATE, the behaviour of the plain ops below): ``amax`` propagates a NaN, so a
+    row (column) that holds one gets scale = NaN and all-zero codes, and qlinear's output row is NaN, as it would be for
+    the unquantised ``F.linear``; an Inf without a NaN gives scale = Inf and all-zero codes (x/Inf = 0, Inf/Inf = NaN -> 0).
+    The two ``where`` lines pin what the plain ops leave open: the NaN scale's payload (canonical quiet NaN 0x7FC00000)
+    and the NaN -> int8 cast (undefined in C++; 0 here)."""
     assert x.dim() == 2 and x.device.type == "cpu"
-    xf = x.to(torch.float32)                                   # exact up-conversion
-    amax = xf.abs().amax(dim=reduce_dim)                       # exact
-    scale = amax / torch.tensor(QMAX, dtype=torch.float32)     # true fp32 division
+    xf = x.to(torch.float32)                                   # Q1 exact up-conversion
+    amax = xf.abs().amax(dim=reduce_dim)                       # Q2 exact; NaN propagates (torch.amax)
+    scale = amax / torch.tensor(QMAX, dtype=torch.float32)     # Q3 true fp32 division
     scale = torch.where(amax == 0, torch.ones_like(scale), scale)   # zero guard (QSPEC Q3)
+    scale = torch.where(scale != scale, torch.full_like(scale, float("nan")), scale)   # Q3: a NaN scale is THE canonical quiet NaN
     s = scale.unsqueeze(reduce_dim)
-    q = torch.round(xf / s)                                    # true division, half-to-even
-    q = torch.clamp(q, -128.0, 127.0).to(torch.int8)
+    q = torch.round(xf / s)                                    # Q4 true division, half-to-even
+    q = torch.where(q != q, torch.zeros_like(q), q)            # Q5 NaN -> 0 (x/NaN, Inf/Inf)
+    q = torch.clamp(q, -128.0, 127.0).to(torch.int8)           # Q6
     return q, scale
 
 

@@ -61,13 +61,20 @@ template <> struct Elem<PQ_F32> {
 };
 
 // ---------------------------------------------------------------- QSPEC scalar rules
-// Q2: NaN-ignoring running max of |x| (compare is false for every NaN).
-__device__ __forceinline__ float amax_step(float amax, float v) {
-    float a = __builtin_fabsf(v);
-    return a > amax ? a : amax;
+// Q2 (QSPEC v2): running max of |x| that PROPAGATES a NaN, as torch.amax does.  On the bit patterns of sign-cleared floats every NaN
+// sorts above +Inf, so an unsigned integer max is the float max with NaN propagation (and costs the same v_max).
+__device__ __forceinline__ float amax_merge(float a, float b) {      // a, b: non-negative, or NaN with the sign bit cleared
+    const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
+    return __builtin_bit_cast(float, x > y ? x : y);
 }
-// Q3: scale = amax / 127 (IEEE division), 1 when amax == 0.
-__device__ __forceinline__ float scale_of(float amax) { return amax == 0.0f ? 1.0f : amax / 127.0f; }
+__device__ __forceinline__ float amax_step(float amax, float v) {
+    return amax_merge(amax, __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu));
+}
+// Q3: scale = amax / 127 (IEEE division), 1 when amax == 0; a NaN scale is THE canonical quiet NaN 0x7FC00000.
+__device__ __forceinline__ float scale_of(float amax) {
+    if (amax != amax) return __builtin_bit_cast(float, 0x7FC00000u);
+    return amax == 0.0f ? 1.0f : amax / 127.0f;
+}
 // Q4-Q6: code = clamp(rne(x / scale), -128, 127), NaN -> 0.   True division: never x * (1/scale).
 __device__ __forceinline__ int code_of(float x, float scale) {
     float t = __builtin_rintf(x / scale);
@@ -80,13 +87,10 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)d << 24);
 }
 
-// wave-wide max of non-negative floats (all 64 lanes get the result)
+// wave-wide NaN-propagating max of sign-cleared floats (all 64 lanes get the result)
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
+    for (int off = 32; off >= 1; off >>= 1) v = amax_merge(v, __shfl_xor(v, off, 64));
     return v;
 }
 

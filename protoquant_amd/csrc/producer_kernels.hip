@@ -224,7 +224,7 @@ __device__ __forceinline__ void fast_encode_vec(const v4u& hv, float s, float r,
 }
 
 // The second half of K1, shared by the producer-fused kernels: row amax of the h vectors held in registers (bit-pattern
-// max, NaN-ignoring float pass when a NaN is present), scale, and the division-free exact encode (or the true-division
+// max: a NaN propagates into the scale), scale, and the division-free exact encode (or the true-division
 // path for NaN/Inf data and extreme scales).  TPR threads own the row; t = thread's index in the row.
 template <int DT, int VPT, int TPR>
 __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t ab, int t, int nvec, bool active, int64_t row,
@@ -239,27 +239,8 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
 #pragma unroll
         for (int w = 0; w < NW; ++w) ab = part[w] > ab ? part[w] : ab;
     }
-    const bool has_nan = amax_bits_has_nan<DT>(ab);
-    float amax = amax_bits_to_f32<DT>(ab);
-    if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare on the registers
-        amax = 0.0f;
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            float f[EPV];
-            Unpack<DT, EPV>::run(hv[i], f);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
-        }
-        amax = wave_max(amax);
-        if constexpr (TPR > kWave) {
-            __syncthreads();
-            if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
-        }
-    }
-    const float s = scale_of(amax);
+    const bool has_nan = amax_bits_has_nan<DT>(ab);          // QSPEC v2: a NaN propagates (scale = canonical NaN, codes 0 by the true-division path)
+    const float s = scale_of(amax_bits_to_f32<DT>(ab));
     if (!active) return;
     if (t == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
@@ -361,7 +342,7 @@ __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __rest
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) amax = part[w] > amax ? part[w] : amax;
+    for (int w = 0; w < 4; ++w) amax = amax_merge(amax, part[w]);
     const float s = scale_of(amax);
     if (threadIdx.x == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
@@ -533,7 +514,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_generic(const void* __restr
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) amax = part[w] > amax ? part[w] : amax;
+    for (int w = 0; w < 4; ++w) amax = amax_merge(amax, part[w]);
     const float s = scale_of(amax);
     if (threadIdx.x == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;

@@ -54,30 +54,8 @@ __global__ __launch_bounds__(256) void quant_rowwise_vec(const uint8_t* __restri
 #pragma unroll
             for (int w = 0; w < 256 / kWave; ++w) ab = part[w] > ab ? part[w] : ab;
         }
-        const bool has_nan = amax_bits_has_nan<DT>(ab);
-        float amax = amax_bits_to_f32<DT>(ab);
-        if (has_nan) {                            // rare, uniform per row group: NaN-ignoring float compare, row re-read from L2
-            amax = 0.0f;
-#pragma unroll 1
-            for (int i = 0; i < VPT; ++i) {
-                const int idx = i * TPR + t;
-                if (idx < nvec) {
-                    float f[EPV];
-                    Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(xr + (int64_t)idx * 16), f);
-#pragma unroll
-                    for (int j = 0; j < EPV; ++j) amax = amax_step(amax, f[j]);
-                }
-            }
-            amax = wave_max(amax);
-            if constexpr (TPR > kWave) {
-                __syncthreads();
-                if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = __builtin_bit_cast(uint32_t, amax);
-                __syncthreads();
-#pragma unroll
-                for (int w = 0; w < 256 / kWave; ++w) { const float o = __builtin_bit_cast(float, part[w]); amax = o > amax ? o : amax; }
-            }
-        }
-        const float s = scale_of(amax);
+        const bool has_nan = amax_bits_has_nan<DT>(ab);      // QSPEC v2: a NaN propagates (scale = canonical NaN, codes 0 by the true-division path)
+        const float s = scale_of(amax_bits_to_f32<DT>(ab));
         if (!active) { if constexpr (RPW == 1) return; else continue; }
         if (t == 0) scale[row] = s;
         int8_t* qr = q + row * ldq;
@@ -199,7 +177,7 @@ __global__ __launch_bounds__(256) void quant_rowwise_generic(const void* __restr
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) amax = part[w] > amax ? part[w] : amax;
+    for (int w = 0; w < 4; ++w) amax = amax_merge(amax, part[w]);
     const float s = scale_of(amax);
     if (threadIdx.x == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
@@ -250,7 +228,7 @@ __global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, i
         for (int j = 0; j < EPV; ++j) {
             float a = m[j];
 #pragma unroll
-            for (int ww = 1; ww < 4; ++ww) a = part[ww][lane][j] > a ? part[ww][lane][j] : a;
+            for (int ww = 1; ww < 4; ++ww) a = amax_merge(a, part[ww][lane][j]);
             atomicMax(&amax_bits[cv * EPV + j], __builtin_bit_cast(uint32_t, a));
         }
     }

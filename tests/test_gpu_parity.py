@@ -9,7 +9,7 @@ import torch
 
 from oracle import c_oracle as C
 from oracle import qspec_numpy as Q
-from tests.gpu_util import TD, bits, same, to_gpu
+from tests.gpu_util import TD, bits, same, same_f, to_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -33,8 +33,8 @@ def test_golden_quantize(pq, golden):
     same(qw.int_data, g["wq"], "wq"); same(qw.scale, g["ws"], "ws")
     qc = pq.quantize(x, axis=0)
     same(qc.int_data, g["x_colq"], "x_colq"); same(qc.scale, g["x_cols"], "x_cols")
-    same(pq.dequantize(q), g["x_deq"], "x_deq")
-    same(pq.dequantize(qc), g["x_coldeq"], "x_coldeq")
+    same_f(pq.dequantize(q), g["x_deq"], g["code"], "x_deq")
+    same_f(pq.dequantize(qc), g["x_coldeq"], g["code"], "x_coldeq")
 
 
 @pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
@@ -45,7 +45,7 @@ def test_golden_gemm_and_qlinear(pq, golden, variant, pq_opt):
     xs = torch.from_numpy(g["xs"]).cuda(); ws = torch.from_numpy(g["ws"]).cuda()
     same(pq.int_mm(xq, wq), g["acc"], "acc")
     bias = to_gpu(g["bias"], g["code"]) if g["bias"] is not None else None
-    same(pq.qlinear_s8(xq, xs, wq, ws, bias, TD[g["code"]]), g["y"], "y")
+    same_f(pq.qlinear_s8(xq, xs, wq, ws, bias, TD[g["code"]]), g["y"], g["code"], "y")
 
 
 def test_golden_qlinear_module(pq, golden):
@@ -58,11 +58,11 @@ def test_golden_qlinear_module(pq, golden):
     m = pq.qlinear.from_linear(lin)
     same(m.wq, g["wq"], "module wq"); same(m.ws, g["ws"], "module ws")
     x = to_gpu(g["x"], g["code"])
-    same(m(x), g["y"], "module y")
+    same_f(m(x), g["y"], g["code"], "module y")
     # [..., K] inputs flatten to [M, K]
     if x.shape[0] % 2 == 0:
         y3 = m(x.reshape(2, -1, x.shape[1]))
-        same(y3.reshape(-1, y3.shape[-1]), g["y"], "module y 3-D")
+        same_f(y3.reshape(-1, y3.shape[-1]), g["y"], g["code"], "module y 3-D")
 
 
 SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), (256, 256, 128),
@@ -118,7 +118,7 @@ def test_quant_vs_oracle(pq, code, rows, cols):
 
 @pytest.mark.parametrize("code", [0, 1, 2])
 def test_quant_special_values(pq, code):
-    """NaN / Inf / signalling NaN / subnormal policy (QSPEC Q2, Q5)."""
+    """NaN / Inf / signalling NaN / subnormal policy (QSPEC v2 Q2, Q3, Q5: a NaN PROPAGATES into its row's / column's scale)."""
     rng = np.random.default_rng(5)
     xf = rng.standard_normal((9, 64)).astype(np.float32)
     xf[1, 3] = np.nan; xf[2, 5] = np.inf; xf[3, :] = 0; xf[4, 0] = -np.inf; xf[4, 1] = np.nan
@@ -126,6 +126,8 @@ def test_quant_special_values(pq, code):
     x = Q.from_f32(xf, code)
     if code != 2:
         x[6, 2] = 0x7F81 if code == 0 else 0x7C01
+    else:
+        x.view(np.uint32)[6, 2] = 0x7F800001
     xg = to_gpu(x, code)
     q = pq.quantize(xg, axis=-1)
     wq, wsc = C.quant_rowwise(x, code)

@@ -16,6 +16,17 @@ def eq(a, b):
     assert np.array_equal(a, b), f"{np.count_nonzero(a != b)} of {a.size} differ"
 
 
+def eq_f(a, b, code):
+    """float outputs: NaNs as a class (QSPEC v2 leaves payload / sign of an arithmetic NaN open), everything else bit for bit"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    na, nb = np.isnan(Q.to_f32(a, code)), np.isnan(Q.to_f32(b, code))
+    assert np.array_equal(na, nb), "NaN positions differ"
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    assert np.array_equal(a[~na], b[~na]), f"{np.count_nonzero(a[~na] != b[~na])} of {a.size} differ"
+
+
 def test_numpy_oracle_matches_golden(golden):
     g = golden
     xq, xs = Q.quantize(g["x"], g["code"], 1)
@@ -26,9 +37,9 @@ def test_numpy_oracle_matches_golden(golden):
     eq(cq, g["x_colq"]); eq(cs, g["x_cols"])
     acc = Q.gemm_s8s8s32(xq, wq)
     eq(acc, g["acc"])
-    eq(Q.epilogue(acc, xs, ws, g["bias"], g["code"]), g["y"])
-    eq(Q.dequantize(xq, xs, 1, g["code"]), g["x_deq"])
-    eq(Q.dequantize(cq, cs, 0, g["code"]), g["x_coldeq"])
+    eq_f(Q.epilogue(acc, xs, ws, g["bias"], g["code"]), g["y"], g["code"])
+    eq_f(Q.dequantize(xq, xs, 1, g["code"]), g["x_deq"], g["code"])
+    eq_f(Q.dequantize(cq, cs, 0, g["code"]), g["x_coldeq"], g["code"])
 
 
 def test_c_oracle_matches_golden(golden):
@@ -40,9 +51,9 @@ def test_c_oracle_matches_golden(golden):
     cq, cs = C.quant_colwise(g["x"], g["code"])
     eq(cq, g["x_colq"]); eq(cs, g["x_cols"])
     eq(C.gemm_s8s8s32(xq, wq), g["acc"])
-    eq(C.qlinear_s8(xq, xs, wq, ws, g["bias"], g["code"]), g["y"])
-    eq(C.dequant(xq, xs, 1, g["code"]), g["x_deq"])
-    eq(C.dequant(cq, cs, 0, g["code"]), g["x_coldeq"])
+    eq_f(C.qlinear_s8(xq, xs, wq, ws, g["bias"], g["code"]), g["y"], g["code"])
+    eq_f(C.dequant(xq, xs, 1, g["code"]), g["x_deq"], g["code"])
+    eq_f(C.dequant(cq, cs, 0, g["code"]), g["x_coldeq"], g["code"])
 
 
 def test_int_gemm_is_exact_integer_arithmetic(golden):
@@ -52,8 +63,13 @@ def test_int_gemm_is_exact_integer_arithmetic(golden):
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])
-def test_c_vs_numpy_on_special_values(dtype):
-    """NaN / Inf / signalling-NaN / subnormal policy (QSPEC Q2,Q5): the two restatements agree."""
+def test_three_forms_agree_on_special_values(dtype):
+    """NaN / Inf / signalling-NaN / subnormal policy (QSPEC v2 Q2, Q3, Q5 — a NaN PROPAGATES into the scale of its row /
+    column): the torch form (plain amax / round around torch._int_mm: the contract-named pipeline), the numpy form and the C
+    form agree — codes and scales bit for bit (a NaN scale is the canonical 0x7FC00000), float outputs with NaNs as a class."""
+    import torch
+    from oracle import torch_ref as R
+    td = {0: torch.bfloat16, 1: torch.float16, 2: torch.float32}[dtype]
     rng = np.random.default_rng(5)
     xf = rng.standard_normal((9, 40)).astype(np.float32)
     xf[1, 3] = np.nan; xf[2, 5] = np.inf; xf[3, :] = 0; xf[4, 0] = -np.inf; xf[4, 1] = np.nan
@@ -61,11 +77,34 @@ def test_c_vs_numpy_on_special_values(dtype):
     x = Q.from_f32(xf, dtype)
     if dtype != 2:
         x[6, 2] = 0x7F81 if dtype == 0 else 0x7C01          # signalling NaN bit pattern
+    else:
+        x.view(np.uint32)[6, 2] = 0x7F800001
+    xt = torch.from_numpy(x.copy()) if dtype == 2 else torch.from_numpy(x.view(np.int16).copy()).view(td)
+
+    def tb(t):
+        t = t.contiguous()
+        return t.numpy() if t.dtype in (torch.float32, torch.int8, torch.int32) else t.view(torch.int16).numpy().view(np.uint16)
+
+    wf = (rng.standard_normal((7, 40)) * 0.02).astype(np.float32)
+    wq, ws = Q.quantize(Q.from_f32(wf, dtype), dtype, 1)
     for axis, cfn in ((1, C.quant_rowwise), (0, C.quant_colwise)):
         qn, sn = Q.quantize(x, dtype, axis)
         qc, sc = cfn(x, dtype)
+        qt, st_ = R.quantize_ref(xt, axis)
         eq(qn, qc); eq(sn, sc)
-        eq(Q.dequantize(qn, sn, axis, dtype), C.dequant(qc, sc, axis, dtype))
+        eq(qn, tb(qt)); eq(sn, tb(st_))
+        nan_rows = np.isnan(Q.to_f32(x, dtype)).any(axis=axis)
+        assert np.array_equal(np.isnan(sn), nan_rows) and nan_rows.sum() >= 3
+        assert np.all(sn.view(np.uint32)[nan_rows] == 0x7FC00000) and not np.take(qn, np.flatnonzero(nan_rows), axis=1 - axis).any()
+        eq_f(Q.dequantize(qn, sn, axis, dtype), C.dequant(qc, sc, axis, dtype), dtype)
+        eq_f(Q.dequantize(qn, sn, axis, dtype), tb(R.dequantize_ref(qt, st_, axis, td)), dtype)
+    # the whole qlinear: a NaN / Inf token row gives a NaN output row in all three forms
+    yn, xqn, xsn, accn = Q.qlinear(x, dtype, wq, ws)
+    yt, xqt, xst, acct = R.qlinear_ref(xt, torch.from_numpy(wq), torch.from_numpy(ws))
+    eq(xqn, tb(xqt)); eq(xsn, tb(xst)); eq(accn, tb(acct)); eq_f(yn, tb(yt), dtype)
+    eq_f(yn, C.qlinear_s8(xqn, xsn, wq, ws, None, dtype), dtype)
+    ynf = Q.to_f32(yn, dtype)
+    assert np.isnan(ynf[[1, 2, 4, 6]]).all() and np.isfinite(ynf[[0, 3, 5, 7, 8]]).all()
 
 
 def test_fp16_bf16_rounding_exhaustive():
@@ -309,7 +348,9 @@ for p in {fixtures!r}:
     cq, cs = C.quant_colwise(z["x"], code); assert np.array_equal(cq, z["x_colq"])
     assert np.array_equal(C.gemm_s8s8s32(xq, wq), z["acc"])
     bias = z["bias"] if "bias" in z.files else None
-    assert np.array_equal(C.qlinear_s8(xq, xs, wq, ws, bias, code), z["y"])
+    y = C.qlinear_s8(xq, xs, wq, ws, bias, code)
+    ok = ~np.isnan(z["y"]) if code == 2 else ((z["y"] & 0x7FFF) <= (0x7F80 if code == 0 else 0x7C00))   # NaNs are compared as a class elsewhere
+    assert np.array_equal(y[ok], z["y"][ok])
     C.dequant(xq, xs, 1, code)
 for p in {prods!r}:
     z = np.load(p); code = int(z["code"])
