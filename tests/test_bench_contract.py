@@ -65,6 +65,28 @@ def test_tp_dry_run_two_ranks_one_gpu():
     assert d["dp"]["scaling"] == "weak" and d["dp"]["value"] > 0 and d["cpu_baseline"] is None
 
 
+def test_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment (the shape of the driver's 1-GPU command): bench.py starts the two ranks
+    itself (children, before any GPU call) and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "3",
+                        "--warmup-seconds", "0.2", "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["scaling"] == "strong"
+    assert "modelled_step_us" in d["config"] and d["config"]["modelled_step_us"] > 0
+
+
+def test_plain_invocation_reports_a_failed_launch():
+    """a rank that dies (here: --share-gpu over RCCL is refused, 'Duplicate GPU') must surface as a non-zero exit and no JSON line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1",
+                        "--M", "-1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
 @pytest.mark.parametrize("args,unit", [(("--workload", "mlp", "--steps", "20", "--warmup", "3"), "TOPS"),
                                        (("--workload", "llama8b", "--tokens", "16", "--steps", "3", "--norms"), "TB/s"),
                                        (("--workload", "llama8b", "--layers", "2", "--steps", "3"), "TOPS"),
