@@ -14,8 +14,10 @@
  *    failing call on this thread.  Nothing throws across the ABI.
  *  - matrices are row-major with explicit leading dimensions in ELEMENTS.
  *  - dtype codes: 0 = bf16, 1 = fp16, 2 = f32.
- *  - numeric contract: QSPEC v1.  int32 accumulators are exact; float stages are
- *    IEEE binary32, round-to-nearest-even, no contraction, true division.
+ *  - numeric contract: QSPEC v2.  int32 accumulators are exact; float stages are
+ *    IEEE binary32, round-to-nearest-even, no contraction, true division.  A NaN in a token row (weight channel)
+ *    PROPAGATES: that row's scale is the canonical quiet NaN 0x7FC00000, its codes are 0 and its qlinear output is NaN —
+ *    what the unquantised linear would give; an Inf gives scale = Inf, codes 0 and a NaN output row.
  */
 #ifndef PQ_HIP_H
 #define PQ_HIP_H
@@ -47,8 +49,14 @@ int32_t pq_version(void);
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
  * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
- * split-K, S = S slices), PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the
- * first call into the library; this call changes a switch afterwards (process-wide, not thread-safe against concurrent launches).  A captured hipGraph keeps the choice that was live at capture time. */
+ * split-K, S = S slices), PQ_FSK_SYMMETRIC (see pq_qlinear_s8), PQ_FAKE_CUS (plan as if the device had n CUs),
+ * PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the first call into the
+ * library; this call changes a switch afterwards.
+ * Threading: the switches live in an immutable snapshot; pq_set_option publishes a modified copy with one atomic pointer
+ * swap, and every other entry point pins the snapshot that is live when it is ENTERED and plans and launches under that
+ * one — so pq_set_option may race with launches on other host threads (each call sees the old or the new set, never a
+ * mixture), and launches from several host threads at once are defined.  There is no other mutable global state in the
+ * library (one-time init aside).  A captured hipGraph keeps the choice that was live at capture time. */
 int32_t pq_set_option(const char* name, const char* value);
 
 /* K1 — per-token dynamic symmetric int8 quantisation: replaces quantize(x) of the contract for an
@@ -96,9 +104,17 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
  * workspace: optional.  pq_qlinear_workspace_bytes(M,N,K) > 0 marks problems (small M*N, long K) for which a
  * 16-byte aligned device workspace of that size enables split-K — partial int32 sums either in slabs of the whole
  * output + an exact integer reduction pass, or handed over between the workgroups of a tile inside the GEMM kernel
- * (flags + per-tile slabs; the call re-initialises the flags itself): results are bit-identical.  The contents need
+ * (tickets + per-tile slabs; the call re-initialises the tickets itself): results are bit-identical.  The contents need
  * not be initialised or preserved; one workspace must not serve two calls that may run concurrently.  With
- * workspace == NULL the single-pass kernel runs instead. */
+ * workspace == NULL the single-pass kernel runs instead.
+ * Liveness of the in-kernel hand-over: the default (ticket) form never waits for a workgroup that may not be running —
+ * the workgroups of a tile that finish first store their partial sums and leave, the last one adds them — so it is safe
+ * under any placement: several such GEMMs on concurrent streams, CU-masked queues, partitioned devices, a co-running
+ * persistent kernel.  It is planned only when tiles x slices <= the CUs the current device reports (a performance rule).
+ * PQ_FSK_SYMMETRIC=1 opts into the symmetric exchange for 2 / 4 slices (each workgroup keeps a part of the tile and
+ * WAITS for its partners' contributions: 2-5 % faster): the caller then guarantees that every workgroup of the launch
+ * can be resident at once — no second fused split-K GEMM in flight on another stream, no CU mask — and the planner
+ * additionally refuses it when tiles x slices exceeds the device's CU count. */
 int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       const int8_t* b, int64_t ldb, const float* b_scale,
                       const void* bias, void* y, int64_t ldy, int32_t out_dtype,

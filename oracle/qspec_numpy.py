@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE — torch-free numpy restatement of QSPEC v1.
+"""TEST INFRASTRUCTURE — torch-free numpy restatement of QSPEC v2.
 
 Parity status: *parity unpinned by the reference* (``/root/reference`` has no source for this path;
 only ``/root/reference/CODE_OF_CONDUCT.md:1-80`` exists).  Pinned instead against

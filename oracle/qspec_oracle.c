@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE — plain-C restatement of QSPEC v1.
+/* TEST INFRASTRUCTURE — plain-C restatement of QSPEC v2.
  *
  * Parity status: PARITY UNPINNED BY THE REFERENCE.  /root/reference holds no source, tests or
  * golden vectors for the dynamic-int8 linear path (only /root/reference/CODE_OF_CONDUCT.md:1-80),

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE — QSPEC v1 as plain torch CPU ops around ``torch._int_mm``.
+"""TEST INFRASTRUCTURE — QSPEC v2 as plain torch CPU ops around ``torch._int_mm``.
 
 Parity status: *parity unpinned by the reference* — ``/root/reference`` contains no source for
 this path (only ``/root/reference/CODE_OF_CONDUCT.md:1-80``), so nothing here can cite a reference
@@ -6,7 +6,7 @@ this path (only ``/root/reference/CODE_OF_CONDUCT.md:1-80``), so nothing here ca
 
 * the integer GEMM is ``torch._int_mm`` itself (``aten::_int_mm(Tensor self, Tensor mat2)``), the
   primitive ``BASELINE.json`` → ``north_star`` names as the CPU oracle;
-* every float stage follows QSPEC v1 (``DESIGN.md`` §2), op for op.
+* every float stage follows QSPEC v2 (``DESIGN.md`` §2), op for op.
 
 This module is what "protoquant's own CPU path" means in ``bench.py``'s ``cpu_baseline`` leg and what
 ``oracle/gen_golden.py`` runs to produce ``tests/golden/*.npz``.  It must only ever be imported from

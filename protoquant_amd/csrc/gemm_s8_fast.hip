@@ -904,18 +904,10 @@ unsigned long long* g_stamps = nullptr;   // dev builds only: set through pq_dev
 void set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 int gemm_debug_flags() { const char* e = getenv("PQ_GEMM_DBG"); return e ? atoi(e) : 0; }
 
-int g_sp128_lc = 1;         // loader / consumer split of the 128 x 256 tile: 1 = 4 consumers + 4 loaders; pq_set_option("PQ_SP128_LC", "0") restores
                             // the 8-wave form (dev builds: 2 = 8 consumers + 4 loaders, 12 waves)
-void set_sp128_lc(int v) { g_sp128_lc = (v < 0 || v > 2) ? 1 : v; }
 // multi-round grids of the 256 x 256 tile through gemm_s8_p3_persist: OFF by default — bit-identical, race-screened, and measured 0 .. 1.7 % SLOWER than one workgroup
 // per tile (profiles/r03_ab_persistent.txt: the hardware dispatcher already overlaps a finished workgroup's store drain with its successor's prologue and
 // balances the tiles dynamically; the persistent form can prefetch only ONE K-tile under the epilogue — the rings are full — and then waits for the second)
-bool g_sp256_persist = false;
-void set_sp256_persist(bool v) { g_sp256_persist = v; }   // pq_set_option("PQ_SP256_PERSIST", "1")
-int g_sp256_asm = 1;        // K-loop variant of kloop_p3_asm.inc (pq_set_option("PQ_SP256_ASM", "n")); 0 = the HIP loop
-void set_sp256_asm(int v) { g_sp256_asm = v < 0 ? 1 : v; }
-bool g_sp256_p3 = true;     // split rings of the 256 x 256 tile: weights 3 slots deep (pq_set_option("PQ_SP256_P3", "0") restores the 2-deep ring)
-void set_sp256_p3(bool v) { g_sp256_p3 = v; }
 
 template <int OUT, int TM, int TN>
 void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi,
@@ -924,27 +916,27 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     const dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
     if constexpr (TM == 128 && TN == 256) {
 #ifdef PQ_ABLATION_BUILD   // 12-wave form (8 consumers): measured 1-3 % slower warm, +-1 % HBM-fed (profiles/r03_ab_lc12.txt) — the tile is ingest-bound, not issue-bound
-        if (g_sp128_lc == 2) {
+        if (opt().sp128_lc == 2) {
             gemm_s8_sp256<OUT, 0, TM, TN, true, false, 0, 8><<<grid, dim3(768), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
             return;
         }
 #endif
-        if (g_sp128_lc) {
+        if (opt().sp128_lc) {
             gemm_s8_sp256<OUT, 0, TM, TN, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
             return;
         }
     }
 #ifdef PQ_ABLATION_BUILD
     if constexpr (OUT == PQ_BF16 && TM == 256 && TN == 256) {
-        if (g_sp256_p3 && gemm_debug_flags() == 1024) {      // stamps only, around an asm K-loop variant
-            switch (K >= 5 * FBK ? g_sp256_asm : 0) {
+        if (opt().sp256_p3 && gemm_debug_flags() == 1024) {      // stamps only, around an asm K-loop variant
+            switch (K >= 5 * FBK ? opt().sp256_asm : 0) {
 #define PQ_ASMS(n) case n: gemm_s8_sp256<OUT, 1024, TM, TN, false, true, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1024, g_stamps, 1); return;
                 PQ_ASMS(1) PQ_ASMS(2) PQ_ASMS(3) PQ_ASMS(6) PQ_ASMS(7) PQ_ASMS(8) PQ_ASMS(9)
 #undef PQ_ASMS
                 default: break;
             }
         }
-        if (g_sp256_p3) {
+        if (opt().sp256_p3) {
             switch (gemm_debug_flags()) {
 #define PQ_ABL3(n) case n: gemm_s8_sp256<OUT, n, TM, TN, false, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, n, g_stamps, 1); return;
                 PQ_ABL3(1) PQ_ABL3(2) PQ_ABL3(3) PQ_ABL3(4) PQ_ABL3(8) PQ_ABL3(1024)
@@ -961,11 +953,11 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
     }
 #endif
     if constexpr (TM == 256 && TN == 256) {
-        if (g_sp256_p3) {
+        if (opt().sp256_p3) {
             // K-tiles 1 .. NT-1 in the hand-allocated asm statement (kloop_p3_asm.inc, variant 1) whenever there are at least five K-tiles;
             // PQ_SP256_ASM=0 keeps the HIP loop (same bits); dev builds: 2 / 3 / 6-9 are the A/B and timing-only variants (bf16 output only)
-            const int av = K >= 5 * FBK ? g_sp256_asm : 0;
-            if (av == 1 && g_sp256_persist && tiles_m * tiles_n > 256) {       // more than one round: one workgroup per CU walks its tiles
+            const int av = K >= 5 * FBK ? opt().sp256_asm : 0;
+            if (av == 1 && opt().sp256_persist && tiles_m * tiles_n > 256) {       // more than one round: one workgroup per CU walks its tiles
                 launch_gemm_p3_persist<OUT>(A, lda, B, ldb, epi, M, N, K, st);
                 return;
             }
@@ -991,8 +983,6 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
 }
 
 // ---- fused split-K (gemm_s8_sp256<..., FSK>): kslices workgroups per 256 x 256 tile, partial sums handed over inside the kernel
-bool g_fsk_sym4 = true;     // four slices: the symmetric exchange (pq_set_option("PQ_FSK_TICKET", "1") takes the ticket form instead: A/B runs)
-void set_fsk_sym4(bool v) { g_fsk_sym4 = v; }
 size_t fsk_workspace_bytes(int64_t M, int64_t N, int kslices) {
     const int64_t ntiles = ((M + 255) / 256) * ((N + 255) / 256);
     return fsk_counter_bytes((int)ntiles, kslices) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
@@ -1005,9 +995,12 @@ bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
     if (hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st) != hipSuccess) return false;   // tickets and ready counts / flags
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
-    if (kslices == 2)
+    // the SYMMETRIC exchanges wait for partner workgroups and are taken only on the caller's promise (PQ_FSK_SYMMETRIC=1: pq_hip.h); the default
+    // ticket form never waits for a workgroup that may not be running
+    const bool sym = opt().fsk_symmetric;
+    if (kslices == 2 && sym)
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 2);
-    else if (kslices == 4 && g_fsk_sym4)
+    else if (kslices == 4 && sym)
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 4);
     else
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, kslices);
@@ -1026,7 +1019,7 @@ void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     EpiArgs epi{nullptr, nullptr, nullptr, slabs, N, 0};
     if constexpr (TM == 256) {      // slices of at least five K-tiles: the split-ring tile with the asm K-loop
-        if (g_sp256_p3 && g_sp256_asm == 1 && K / kslices >= 5 * FBK) {
+        if (opt().sp256_p3 && opt().sp256_asm == 1 && K / kslices >= 5 * FBK) {
             gemm_s8_sp256<OUT_I32, 0, 256, 256, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
             return;
         }
@@ -1293,14 +1286,12 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     }
 }
 
-bool g_ring_lc = true;      // loader / consumer split (pq_set_option("PQ_RING_LC", "0") restores the 4-wave form)
-void set_ring_lc(bool v) { g_ring_lc = v; }
 
 template <int OUT>
 void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
                          int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + R_TILE - 1) / R_TILE), tiles_n = (int)((N + R_TILE - 1) / R_TILE);
-    if (g_ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
     else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
 }
 template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

@@ -140,9 +140,7 @@ static int skinny_ks(int64_t blocks, int64_t K, int tiles) {
 }
 // two weight blocks per wave once that still leaves >= 192 workgroups (measured: N = 6144 10.2 -> 8.3 us at 16 tokens, lm_head
 // 148 -> 124 us; N = 4096 would drop to 128 workgroups: 6.3 -> 8.1 us)
-int g_skinny_rb = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_SKINNY_RB"), or the environment read once in pq_api.hip)
-void set_skinny_rb(int v) { g_skinny_rb = v; }
-static bool skinny_rb2(int64_t N) { return g_skinny_rb ? g_skinny_rb == 2 : N >= 6144; }
+static bool skinny_rb2(int64_t N) { const int rb = opt().skinny_rb; return rb ? rb == 2 : N >= 6144; }     // PQ_SKINNY_RB: 0 auto, 1 / 2 forced
 
 template <int OUT>
 void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <atomic>
 #include <mutex>
 
 #include "gemm_epilogue.h"
@@ -24,19 +25,7 @@ template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
 template <int OUT> bool launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
 size_t fsk_workspace_bytes(int64_t, int64_t, int);
-void set_fsk_sym4(bool);
 void set_stamp_buffer(unsigned long long*);
-void set_skinny_rb(int);
-void set_k1_rpw(int);
-void set_k1_st16(bool);
-void set_k1_lds(int);
-void set_ring_lc(bool);
-void set_sp128_lc(int);
-void set_sp256_p3(bool);
-void set_sp256_asm(int);
-void set_sp256_persist(bool);
-void set_silu_tpr(int);
-void set_rms_wave_max(int);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
 void launch_half_encode_check(int, unsigned long long*, hipStream_t);
 void launch_silu_short_check(int, unsigned long long*, hipStream_t);
@@ -73,66 +62,92 @@ Variant parse_variant(const char* e) {
     return V_AUTO;
 }
 
-// Behaviour switches (tests / experiments).  The environment is read ONCE, at the first call into the library (a getenv per
-// launch is host time on the hot path, and a switch that a captured hipGraph freezes must not look live); tests that need
-// another setting within one process use pq_set_option().
-struct Options {
-    int variant = V_AUTO;
-    bool no_tailsplit = false, no_splitk = false;
-    int force_splitk = 0;
-    int fsk = -1;            // fused split-K: -1 = by plan (fsk_plan), 0 = never, S > 1 = S slices whenever the shape admits them (experiments)
-    // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
-    // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
-    int (*roctx_push)(const char*) = nullptr;
-    int (*roctx_pop)() = nullptr;
-};
-Options g_opt;
+// Behaviour switches (tests / experiments): pq::Options (pq_common.h), one immutable snapshot per state.  The environment is read ONCE, at the
+// first call into the library (a getenv per launch is host time on the hot path, and a switch that a captured hipGraph freezes must not look
+// live); pq_set_option() publishes a modified copy by one atomic pointer swap.  Every C-ABI entry point pins the live snapshot for its own
+// duration (CallScope): planning and launching happen under ONE set of switches, and concurrent calls from several host threads are defined.
+std::atomic<const pq::Options*> g_live{nullptr};
+std::mutex g_opt_mu;                       // writers only (pq_set_option, the environment pass)
 std::once_flag g_opt_once;
+thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by the C-ABI call in progress on this thread
+thread_local int tl_depth = 0;
+
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_TICKET", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FAKE_CUS", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
-bool apply_option(const char* name, const char* value) {
-    if (!strcmp(name, "PQ_FORCE_VARIANT")) g_opt.variant = parse_variant(value);
-    else if (!strcmp(name, "PQ_NO_TAILSPLIT")) g_opt.no_tailsplit = value && *value;
-    else if (!strcmp(name, "PQ_NO_SPLITK")) g_opt.no_splitk = value && *value;
-    else if (!strcmp(name, "PQ_FORCE_SPLITK")) g_opt.force_splitk = value && *value ? atoi(value) : 0;
-    else if (!strcmp(name, "PQ_FSK")) g_opt.fsk = value && *value ? atoi(value) : -1;
-    else if (!strcmp(name, "PQ_FSK_TICKET")) pq::set_fsk_sym4(!(value && *value == '1'));
-    else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) pq::set_rms_wave_max(value && *value ? atoi(value) : -1);
-    else if (!strcmp(name, "PQ_SILU_TPR")) pq::set_silu_tpr(value && !strcmp(value, "256") ? 256 : 0);
-    else if (!strcmp(name, "PQ_SP128_LC")) pq::set_sp128_lc(value && *value ? atoi(value) : 1);
-    else if (!strcmp(name, "PQ_SP256_P3")) pq::set_sp256_p3(!(value && *value == '0'));
-    else if (!strcmp(name, "PQ_SP256_ASM")) pq::set_sp256_asm(value && *value ? atoi(value) : -1);     // "" = default (1)
-    else if (!strcmp(name, "PQ_SP256_PERSIST")) pq::set_sp256_persist(value && *value == '1');
-    else if (!strcmp(name, "PQ_RING_LC")) pq::set_ring_lc(!(value && *value == '0'));
-    else if (!strcmp(name, "PQ_K1_LDS")) pq::set_k1_lds(value ? atoi(value) : 0);
-    else if (!strcmp(name, "PQ_K1_ST16")) pq::set_k1_st16(value && *value == '1');
-    else if (!strcmp(name, "PQ_K1_RPW")) pq::set_k1_rpw(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
-    else if (!strcmp(name, "PQ_SKINNY_RB")) pq::set_skinny_rb(value && *value == '2' ? 2 : (value && *value == '1' ? 1 : 0));
+bool apply_option(pq::Options& o, const char* name, const char* value) {
+    const bool set = value && *value;
+    const int iv = set ? atoi(value) : 0;
+    if (!strcmp(name, "PQ_FORCE_VARIANT")) o.variant = parse_variant(value);
+    else if (!strcmp(name, "PQ_NO_TAILSPLIT")) o.no_tailsplit = set;
+    else if (!strcmp(name, "PQ_NO_SPLITK")) o.no_splitk = set;
+    else if (!strcmp(name, "PQ_FORCE_SPLITK")) o.force_splitk = iv;
+    else if (!strcmp(name, "PQ_FSK")) o.fsk = set ? iv : -1;
+    else if (!strcmp(name, "PQ_FSK_SYMMETRIC")) o.fsk_symmetric = set && *value == '1';
+    else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
+    else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) o.rms_wave_max = !set || iv < 0 ? 256 : (iv > 512 ? 512 : iv);
+    else if (!strcmp(name, "PQ_SILU_TPR")) o.silu_tpr = set && !strcmp(value, "256") ? 256 : 0;
+    else if (!strcmp(name, "PQ_SP128_LC")) o.sp128_lc = !set || iv < 0 || iv > 2 ? 1 : iv;
+    else if (!strcmp(name, "PQ_SP256_P3")) o.sp256_p3 = !(set && *value == '0');
+    else if (!strcmp(name, "PQ_SP256_ASM")) o.sp256_asm = !set || iv < 0 ? 1 : iv;     // "" = default (1)
+    else if (!strcmp(name, "PQ_SP256_PERSIST")) o.sp256_persist = set && *value == '1';
+    else if (!strcmp(name, "PQ_RING_LC")) o.ring_lc = !(set && *value == '0');
+    else if (!strcmp(name, "PQ_K1_LDS")) o.k1_lds = iv < 0 ? 0 : (iv > 65536 ? 65536 : iv);
+    else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
+    else if (!strcmp(name, "PQ_K1_RPW")) o.k1_rpw = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
+    else if (!strcmp(name, "PQ_SKINNY_RB")) o.skinny_rb = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
     else return false;
     return true;
 }
-const Options& options() {
+const pq::Options* live_options() {
     std::call_once(g_opt_once, [] {
+        auto* o = new pq::Options();
         for (const char* n : kOptionNames)
-            if (const char* v = getenv(n)) apply_option(n, v);
+            if (const char* v = getenv(n)) apply_option(*o, n, v);
         if (const char* r = getenv("PQ_ROCTX")) {
+            // PQ_ROCTX=1: every C-ABI entry point pushes / pops a roctx range (quant / gemm / ...), so a rocprofv3 --marker-trace
+            // timeline shows the path's stages by name.  The marker library is dlopen'ed on first use; absent library = no ranges.
             if (*r && *r != '0') {
                 void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
                 if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
                 if (h) {
-                    g_opt.roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
-                    g_opt.roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-                    if (!g_opt.roctx_push || !g_opt.roctx_pop) g_opt.roctx_push = nullptr, g_opt.roctx_pop = nullptr;
+                    o->roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                    o->roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                    if (!o->roctx_push || !o->roctx_pop) o->roctx_push = nullptr, o->roctx_pop = nullptr;
                 }
             }
         }
+        g_live.store(o, std::memory_order_release);
     });
-    return g_opt;
+    return g_live.load(std::memory_order_acquire);
+}
+const pq::Options& options() { return tl_opt ? *tl_opt : *live_options(); }
+
+// pins the live snapshot for one C-ABI call on this thread (re-entrant: pq_qlinear_dyn calls pq_quant_rowwise and pq_qlinear_s8 under ITS snapshot)
+struct CallScope {
+    CallScope() { if (tl_depth++ == 0) tl_opt = live_options(); }
+    ~CallScope() { if (--tl_depth == 0) tl_opt = nullptr; }
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+};
+
+// CUs of the current device (hipDeviceGetAttribute, cached per device ordinal; a CU-masked or partitioned device reports fewer); PQ_FAKE_CUS overrides
+int device_cus() {
+    if (options().fake_cus > 0) return options().fake_cus;
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 Variant forced_variant() { return static_cast<Variant>(options().variant); }
 
-struct Range {      // roctx range for the lifetime of one C-ABI call (host side: it brackets the launches, which are asynchronous)
+struct Range {      // one C-ABI call: pins the option snapshot (CallScope) and, with PQ_ROCTX, a roctx range (host side: it brackets the asynchronous launches)
+    CallScope scope_;
     bool on;
     explicit Range(const char* name) : on(options().roctx_push != nullptr) { if (on) options().roctx_push(name); }
     ~Range() { if (on) options().roctx_pop(); }
@@ -233,14 +248,20 @@ bool bad_mat(const void* p, int64_t rows, int64_t cols, int64_t ld) {
 
 }  // namespace
 
+namespace pq {
+const Options& opt() { return options(); }
+}  // namespace pq
+
 extern "C" {
 
 int32_t pq_version(void) { return PQ_ABI_VERSION; }
 
 int32_t pq_set_option(const char* name, const char* value) {
     if (!name) return fail(PQ_ERR_BAD_ARG, "pq_set_option: null name");
-    options();                                   // the environment is consumed first, so a later call_once cannot undo this
-    if (!apply_option(name, value)) return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name);
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    auto* o = new pq::Options(*live_options());  // (the environment is consumed first, so a later call_once cannot undo this)
+    if (!apply_option(*o, name, value)) { delete o; return fail(PQ_ERR_BAD_ARG, "pq_set_option: unknown option %s", name); }
+    g_live.store(o, std::memory_order_release);  // calls already in flight keep the snapshot they pinned; the old one is never freed
     return PQ_OK;
 }
 const char* pq_last_error(void) { return g_err; }
@@ -378,16 +399,21 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
 static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     const int f = options().fsk;
     if (f == 0 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
-    if (f > 1) return (K % (128 * f) == 0 && K / f >= 5 * 128) ? f : 0;
+    // (experiments: any grid in the ticket form, which never waits for a workgroup that is not running; the symmetric forms only when every workgroup is resident)
+    if (f > 1) return (K % (128 * f) == 0 && K / f >= 5 * 128 && (!options().fsk_symmetric || f * (((M + 255) / 256) * ((N + 255) / 256)) <= device_cus())) ? f : 0;
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    if (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) return 2;
+    // residency guard: the slices of a tile hand over inside the kernel, one workgroup per CU (160 KiB of LDS): plan it only when the whole grid fits the CUs
+    // this device reports (a CU-masked or partitioned device reports fewer) — otherwise the two-pass split-K or the single-pass tile runs
+    const int cus = device_cus();
+    if (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) return 2 * t256 <= cus ? 2 : 0;
     // the quarter-filled grid with a very long K (the Llama-70B `down` shard, 4096 x 1024 x 28672): four slices, four-way symmetric exchange — 91.3 / 92.1 us
     // (warm / HBM-fed) against 98.9 / 99.3 for the two-pass split-K and 99 / 128 for the ring tile; at K = 16384 the ring tile still wins (r03_ab_fsk.txt, run 6)
-    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) return 4;
+    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) return 4 * t256 <= cus ? 4 : 0;
     return 0;
 }
 
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    CallScope scope_;
     if (const int f = fsk_plan(M, N, K)) return pq::fsk_workspace_bytes(M, N, f);
     int tm = 256;
     const int s = splitk_plan(M, N, K, &tm);
@@ -472,6 +498,7 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t pq_qlinear_dyn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    CallScope scope_;
     if (M < 0 || N < 0 || K < 0) return 0;
     return align256((size_t)M * (size_t)K) + align256((size_t)M * sizeof(float)) + pq_qlinear_workspace_bytes(M, N, K);
 }
@@ -479,6 +506,7 @@ size_t pq_qlinear_dyn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 int32_t pq_qlinear_dyn(const void* x, int32_t dtype, int64_t ld_x, const int8_t* w, int64_t ldw, const float* w_scale,
                        const void* bias, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, void* workspace,
                        size_t workspace_bytes, void* stream) {
+    CallScope scope_;           // K1 and the GEMM of this call plan and launch under ONE snapshot
     if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_dyn: unknown dtype %d", dtype);
     if (M < 0 || N < 0 || K < 0) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_dyn: negative size");
     if (M == 0 || N == 0) return PQ_OK;
@@ -518,6 +546,7 @@ void pq_dev_set_stamp_buffer(unsigned long long* p) { pq::set_stamp_buffer(p); }
 #endif
 
 const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    CallScope scope_;
     // alignment of the pointers is unknown here: assume 16-byte aligned bases
     switch (pick_variant(reinterpret_cast<const int8_t*>(16), lda, reinterpret_cast<const int8_t*>(16), ldb, M, N, K)) {
         case V_SP256_16: {

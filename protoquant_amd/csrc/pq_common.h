@@ -1,4 +1,4 @@
-// pq_common.h — shared device helpers for the gfx950 dynamic-int8 linear path (QSPEC v1).
+// pq_common.h — shared device helpers for the gfx950 dynamic-int8 linear path (QSPEC v2).
 // gfx950 only: 64-wide wavefronts are hard-coded.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,6 +15,36 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- behaviour switches (host side)
+// Every switch of the library lives in ONE immutable snapshot.  pq_set_option() (and the one-time pass over the environment) builds a modified
+// copy and publishes it with one atomic pointer swap; every C-ABI entry point pins the snapshot that is live when it is entered (thread-local,
+// pq_api.hip: CallScope) and the planners and launchers of that call read nothing else — so a call plans and launches under ONE consistent set of
+// switches whatever other host threads set meanwhile, and concurrent launches from several host threads are defined.  Snapshots are never freed
+// (a few hundred bytes per pq_set_option call; tests and experiments only).
+struct Options {
+    int variant = 0;                 // PQ_FORCE_VARIANT (pq_api.hip: enum Variant; 0 = auto)
+    bool no_tailsplit = false, no_splitk = false;
+    int force_splitk = 0;
+    int fsk = -1;                    // fused split-K: -1 = by plan (fsk_plan), 0 = never, S > 1 = S slices whenever the shape admits them (experiments)
+    bool fsk_symmetric = false;      // PQ_FSK_SYMMETRIC=1: the symmetric exchange for 2 / 4 slices (waits for partner workgroups: see pq_hip.h); default: the ticket form
+    int fake_cus = 0;                // PQ_FAKE_CUS=n: plan as if the device had n CUs (tests of the residency guard)
+    int skinny_rb = 0;               // 0 auto, 1 / 2 forced
+    int k1_rpw = 0;                  // 0 auto, 1 / 2 forced
+    bool k1_st16 = false;            // 16-byte code stores in K1: A/B in profiles/r03_k1_st16.txt
+    int k1_lds = 0;                  // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU
+    bool ring_lc = true;             // loader / consumer split of the 128 x 128 ring tile
+    int sp128_lc = 1;                // loader / consumer split of the 128 x 256 tile: 1 = 4 consumers + 4 loaders, 0 = 8 symmetric waves, 2 = 12 waves (dev builds)
+    bool sp256_p3 = true;            // split rings of the 256 x 256 tile (weights 3 slots deep)
+    int sp256_asm = 1;               // K-loop variant of kloop_p3_asm.inc; 0 = the HIP loop
+    bool sp256_persist = false;
+    int silu_tpr = 0;                // 0 auto; 256 forces the 256-thread layout on wide rows
+    int rms_wave_max = 256;
+    int (*roctx_push)(const char*) = nullptr;      // PQ_ROCTX=1 (environment only)
+    int (*roctx_pop)() = nullptr;
+};
+// the snapshot pinned by the C-ABI call in progress on this thread (outside a call: the live one)
+const Options& opt();
 
 // ---------------------------------------------------------------- write-through global stores
 // Output streams (codes, dequantised tiles, y) are stored with the sc1 cache policy: the line is written through to the memory side

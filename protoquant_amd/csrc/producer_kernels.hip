@@ -548,10 +548,6 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 // 512 vectors (a 4096-wide bf16 hidden state): 118 VGPRs, 4 waves per SIMD.  Measured in round 2 (profiles/r02_k1n_layout.txt): at 512
 // vectors the 256-thread block per row (2 vectors per thread, ~44 VGPRs) is 10 % faster at 4096 rows (15.7 -> 14.2 us) and equal at 16384;
 // at 256 vectors the wave layout wins (8.7 vs 9.6 us).  Same bits either way (QSPEC N1-N3 pins the order of the sum).
-int g_rms_wave_max = 256;
-void set_rms_wave_max(int v) { g_rms_wave_max = v < 0 ? 256 : (v > 512 ? 512 : v); }
-int g_silu_tpr = 0;       // 0 auto; 256 forces the 256-thread layout on wide rows (pq_set_option("PQ_SILU_TPR", "256"))
-void set_silu_tpr(int v) { g_silu_tpr = v; }
 
 template <int DT, int TPR, bool WRITE_H>
 static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const uint8_t* u, int64_t ldu_b, int64_t rows, int nvec,
@@ -595,7 +591,7 @@ void silu_mul_quant_dispatch(const void* g, int64_t ldg, const void* u, int64_t 
         const int vpt = pow2((nvec + 63) / 64);
         if (h_out) launch_silu_mul_vec<DT, 64, true>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, ldh * kb, st);
         else launch_silu_mul_vec<DT, 64, false>(vpt, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, hb, 0, st);
-    } else if (nvec > 1024 && nvec <= 1536 && g_silu_tpr != 256) {
+    } else if (nvec > 1024 && nvec <= 1536 && opt().silu_tpr != 256) {
         // rows of 1025..1536 vectors (e.g. 11008 columns): 512 threads x 3 vectors fill 90 % of their slots where 256 threads x 8
         // fill 67 % (the kernel is VALU-bound, idle slots are idle lanes): 2048 x 11008 30.4 -> 28.1 us.  At 1537..2048 vectors
         // (14336, 16384 columns) both layouts have the same slots and measured the same (profiles/r02_k1s_threads_per_row.txt).
@@ -625,7 +621,7 @@ void rmsnorm_quant_dispatch(const void* x, int64_t ldx, const void* wgt, float e
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(wgt);
     uint8_t* hb = reinterpret_cast<uint8_t*>(h_out);
     const int64_t kb = Elem<DT>::kBytes;
-    if (nvec <= g_rms_wave_max) {         // one wave per row (rmsnorm_quant_wave): VPT in {4, 8} keeps i & 3 meaningful
+    if (nvec <= opt().rms_wave_max) {         // one wave per row (rmsnorm_quant_wave): VPT in {4, 8} keeps i & 3 meaningful
         const dim3 wgrid((unsigned)((rows + 3) / 4));
 #define PQ_RMSW_LAUNCH(V)                                                                                                                 \
     do {                                                                                                                              \

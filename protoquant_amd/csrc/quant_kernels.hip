@@ -1,7 +1,7 @@
 // quant_kernels.hip — K1 per-token row quant, K2 per-channel column quant, dequant (gfx950).
 // All three are HBM-bound byte movers: 16-byte coalesced loads, one read of x for K1 (the row lives
 // in registers between the amax reduction and the encode), wavefront shuffles + one LDS hop for the
-// reductions.  Arithmetic follows QSPEC v1 exactly (true fp32 division, RNE, no contraction).
+// reductions.  Arithmetic follows QSPEC v2 exactly (true fp32 division, RNE, no contraction).
 #include "quant_device.h"
 
 namespace pq {
@@ -343,51 +343,46 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
 // host-side launchers (called from pq_api.hip)
 static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-bool g_k1_st16 = false;   // 16-byte code stores in K1 (pq_set_option("PQ_K1_ST16", "1")): A/B in profiles/r03_k1_st16.txt
-void set_k1_st16(bool v) { g_k1_st16 = v; }
-int g_k1_rpw = 0;     // 0 auto, 1 / 2 forced (pq_set_option("PQ_K1_RPW"))
-void set_k1_rpw(int v) { g_k1_rpw = v; }
-int g_k1_lds = 0;     // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU (pq_set_option("PQ_K1_LDS"))
-void set_k1_lds(int v) { g_k1_lds = v < 0 ? 0 : (v > 65536 ? 65536 : v); }
-
 template <int DT, int TPR>
 static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, int64_t ldx_bytes, int8_t* q,
                                int64_t ldq, float* scale, hipStream_t st) {
     constexpr int RPB = 256 / TPR;
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+    const size_t k1_lds = (size_t)opt().k1_lds;
     if constexpr (TPR == kWave) {
         // two rows per wave: built to overlap one row's stores with the other's loads, and measured SLOWER on every shape
         // (profiles/r02_k1_rows_per_wave.txt: 4096 x 4096 9.56 -> 10.49 us, 16384 x 4096 31.6 -> 32.5 us): the one-row kernel
         // already runs at 76-80 % of 8 TB/s once the problem is large enough (4096 x 8192, 16384 x 4096); what keeps
         // 4096 x 4096 at 66 % is ~1.5 us of launch ramp and tail on an 8 us transfer, not the phase structure.  Kept
         // selectable (pq_set_option("PQ_K1_RPW", "2")) so the measurement can be repeated.
-        const bool two = g_k1_rpw == 2;
+        const Options& o = opt();
+        const bool two = o.k1_rpw == 2;
         if (two && vpt <= 8) {
             const dim3 grid2((unsigned)((rows + 2 * RPB - 1) / (2 * RPB))), block(256);
             switch (vpt) {
-                case 1: quant_rowwise_vec<DT, 1, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                case 2: quant_rowwise_vec<DT, 2, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                case 4: quant_rowwise_vec<DT, 4, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                default: quant_rowwise_vec<DT, 8, TPR, 2><<<grid2, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 1: quant_rowwise_vec<DT, 1, TPR, 2><<<grid2, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 2: quant_rowwise_vec<DT, 2, TPR, 2><<<grid2, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 4: quant_rowwise_vec<DT, 4, TPR, 2><<<grid2, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                default: quant_rowwise_vec<DT, 8, TPR, 2><<<grid2, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
             }
         }
     }
     const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(256);
     if constexpr (TPR == kWave && Elem<DT>::kBytes == 2) {
-        if (g_k1_st16 && (nvec & 1) == 0 && (ldq & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 && vpt >= 2 && vpt <= 8) {
+        if (opt().k1_st16 && (nvec & 1) == 0 && (ldq & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 && vpt >= 2 && vpt <= 8) {
             switch (vpt) {
-                case 2: quant_rowwise_vec<DT, 2, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                case 4: quant_rowwise_vec<DT, 4, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
-                default: quant_rowwise_vec<DT, 8, TPR, 1, true><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 2: quant_rowwise_vec<DT, 2, TPR, 1, true><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                case 4: quant_rowwise_vec<DT, 4, TPR, 1, true><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
+                default: quant_rowwise_vec<DT, 8, TPR, 1, true><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); return;
             }
         }
     }
     switch (vpt) {
-        case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 4: quant_rowwise_vec<DT, 4, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        case 8: quant_rowwise_vec<DT, 8, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        default: quant_rowwise_vec<DT, 16, TPR><<<grid, block, (size_t)g_k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 1: quant_rowwise_vec<DT, 1, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 4: quant_rowwise_vec<DT, 4, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 8: quant_rowwise_vec<DT, 8, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        default: quant_rowwise_vec<DT, 16, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
     }
 }
 

@@ -3,7 +3,7 @@
 forward(x[..., K]) = K1 row-quant(x) -> K3 s8xs8->s32 MFMA GEMM -> K4 fused (row-scale x col-scale
 (+bias)) epilogue, all inside libpq_hip.so.  Weights are quantised once, per output channel, when
 the module is built.  Reference definitions are absent from the mount (/root/reference holds only
-CODE_OF_CONDUCT.md:1-80); semantics follow QSPEC v1."""
+CODE_OF_CONDUCT.md:1-80); semantics follow QSPEC v2."""
 from __future__ import annotations
 
 import torch

@@ -2,7 +2,7 @@
 
 The reference's own definitions are absent from the mount (/root/reference holds only
 CODE_OF_CONDUCT.md:1-80), so signatures are build-defined and numerics follow
-QSPEC v1.  All arithmetic happens in libpq_hip.so (HIP, gfx950)."""
+QSPEC v2.  All arithmetic happens in libpq_hip.so (HIP, gfx950)."""
 from __future__ import annotations
 
 from dataclasses import dataclass

@@ -63,18 +63,24 @@ def convert_checkpoint(state_dict: dict, *, device="cuda", is_linear: Callable[[
       (``<p>.local.*``).  sharded_gated_mlp: MLP prefixes stored as ShardedGatedMLP (gate/up column shards fused, down row
       shard with full-row scales).  A pattern is a module prefix, compared LITERALLY ("model.layers.0.mlp": its dots are dots, a name
       with brackets or a plus sign is fine), or a regular expression given explicitly: a compiled ``re.Pattern`` or a string that
-      starts with ``re:`` (matched with re.fullmatch)."""
+      starts with ``re:`` (matched with re.fullmatch).  A pattern that matches no module raises KeyError (a plain string that looks like a
+      regular expression gets a hint): the checkpoint is never written silently unfused / unsharded."""
+    gated_mlp, column_sharded, row_sharded, sharded_gated_mlp = (list(v) for v in (gated_mlp, column_sharded, row_sharded, sharded_gated_mlp))
+    hits: dict[int, int] = {}          # id(pattern) -> modules it matched: a pattern that matches NOTHING is an error, not a silently unsharded checkpoint
+
     def match(patterns, name):
+        found = False
         for p in patterns:
             if isinstance(p, re.Pattern):
-                if p.fullmatch(name):
-                    return True
+                ok = p.fullmatch(name) is not None
             elif isinstance(p, str) and p.startswith("re:"):
-                if re.fullmatch(p[3:], name):
-                    return True
-            elif p == name:
-                return True
-        return False
+                ok = re.fullmatch(p[3:], name) is not None
+            else:
+                ok = p == name
+            if ok:
+                hits[id(p)] = hits.get(id(p), 0) + 1
+                found = True
+        return found
 
     if model is not None:
         linear_names = {n for n, m in model.named_modules() if isinstance(m, nn.Linear)}
@@ -144,6 +150,14 @@ def convert_checkpoint(state_dict: dict, *, device="cuda", is_linear: Callable[[
         else:
             put(p, wq, ws, bias)
         used.add(p)
+    for kind, patterns in (("gated_mlp", gated_mlp), ("sharded_gated_mlp", sharded_gated_mlp), ("column_sharded", column_sharded), ("row_sharded", row_sharded)):
+        for p in patterns:
+            if hits.get(id(p), 0) == 0:
+                shown = p.pattern if isinstance(p, re.Pattern) else p
+                hint = ""
+                if isinstance(p, str) and not p.startswith("re:") and re.search(r"[\\*+?\[\](){}|^$]", p):
+                    hint = ' — it looks like a regular expression: plain strings are compared LITERALLY, write "re:' + p + '" or pass a compiled re.Pattern'
+                raise KeyError(f"convert_checkpoint: {kind} pattern {shown!r} matches no linear module of the checkpoint{hint}")
     for k, v in sd.items():
         base = k.rsplit(".", 1)[0]
         if base in used and (k.endswith(".weight") or k.endswith(".bias")):

@@ -23,22 +23,40 @@ def pq():
     return protoquant_amd
 
 
-def _spawn(world, port):
-    procs = []
+def _spawn(world, port, timeout=600):
+    """One child per rank, output to temporary files (a PIPE nobody reads fills up and stalls its rank).  All children are polled TOGETHER: as soon as one
+    exits non-zero the others — which would otherwise sit in the collective until the timeout, holding the GPUs — are killed."""
+    import tempfile
+    import time
+    procs, files = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py")], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        f = tempfile.TemporaryFile(mode="w+")
+        files.append(f)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py")], env=env, stdout=f, stderr=subprocess.STDOUT, text=True))
+    t0 = time.time()
+    failed = timed_out = False
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = any(c not in (None, 0) for c in codes)
+        timed_out = time.time() - t0 > timeout
+        if failed or timed_out or all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    if failed or timed_out:
+        time.sleep(1.0)                      # let the other ranks print their own error, if they have one
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append((p.returncode, o))
+    for p, f in zip(procs, files):
+        p.wait()
+        f.seek(0)
+        outs.append((p.returncode, f.read()))
+        f.close()
+    if timed_out and not failed:
+        raise subprocess.TimeoutExpired("rccl_rank_worker.py", timeout, output="\n".join(o[-1500:] for _, o in outs))
     return outs
 
 

@@ -251,9 +251,9 @@ def test_forced_splitk_slices_on_the_asm_loop(pq, M, N, S, NT, code, bias, pq_op
                                                  (640, 256, 2, 9, 0, True), (256, 777, 5, 10, 0, False), (130, 130, 2, 11, 2, True), (2048, 4096, 2, 43, 0, False),
                                                  (1024, 1024, 4, 16, 1, True), (2048, 4096, 2, 43, 0, True)])
 def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
-    """PQ_FSK=S (forced here; the plan picks S = 2 for half-filled grids with a long K): the K-slices of a 256 x 256 tile hand their partial sums over INSIDE the GEMM kernel — S = 2: the symmetric exchange between
-    workgroups 2 p and 2 p + 1 (each finishes one column half), S = 4: the four-way symmetric exchange (a quarter each), other S: the ticket form (the last
-    workgroup of a tile to arrive adds the others' slabs; PQ_FSK_TICKET=1 takes it for S = 4 too);
+    """PQ_FSK=S (forced here; the plan picks S = 2 for half-filled grids with a long K): the K-slices of a 256 x 256 tile hand their partial sums over INSIDE the GEMM kernel — the ticket form (the last
+    workgroup of a tile to arrive adds the others' slabs: the default, placement-independent) and, with PQ_FSK_SYMMETRIC=1, S = 2: the symmetric exchange between
+    workgroups 2 p and 2 p + 1 (each finishes one column half), S = 4: the four-way symmetric exchange (a quarter each);
     every ring phase at the exit (NT = 5 .. 11), ragged M and N (edge tiles through the direct epilogue), a full-size half-filled grid (the cfg-3 `down`
     GEMM, all 256 CUs in the exchange at once), repeated calls on one workspace (the launcher re-zeroes the flags): == the oracle and == the default dispatch."""
     from protoquant_amd import _lib
@@ -272,11 +272,10 @@ def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
     pq_opt("PQ_FSK", str(S))
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == ((tiles * 4 * (4 if S == 4 else 2) + 255) // 256) * 256 + tiles * (S - 1) * 256 * 256 * 4
-    for rep in range(4):
-        if S == 4 and rep == 3:
-            pq_opt("PQ_FSK_TICKET", "1")
+    for rep in range(6):
+        pq_opt("PQ_FSK_SYMMETRIC", "1" if rep >= 3 else "")          # three launches in the ticket form, three in the symmetric form (S = 2 / 4; other S: ticket again)
         y = pq.qlinear_s8(*args)
-        assert torch.equal(y.view(torch.uint8), y_def.view(torch.uint8)), "fused split-K y"
+        assert torch.equal(y.view(torch.uint8), y_def.view(torch.uint8)), f"fused split-K y (rep {rep})"
 
 
 @pytest.mark.parametrize("M", [1, 2, 7, 16, 17, 32, 33, 48, 64])

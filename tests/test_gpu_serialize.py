@@ -196,3 +196,9 @@ def test_convert_with_model_quantises_only_nn_linear(pq):
     assert "blocks.a+b.local.wq" in conv and tuple(conv["blocks.a+b.local.wq"].shape) == (16, 48)       # rank 1 of 2: rows 16..31
     heur = S.convert_checkpoint(sd)
     assert "conv1d.wq" in heur                                                # what the heuristic alone does (documented, hence `model=`)
+    # a pattern that matches nothing is an error (a plain string that used to be read as a regex would otherwise leave the checkpoint unsharded, silently)
+    with pytest.raises(KeyError, match="looks like a regular expression"):
+        S.convert_checkpoint(sd, model=m, column_sharded=[r"blocks\..*"], world=2, rank=1)
+    with pytest.raises(KeyError, match="matches no linear module"):
+        S.convert_checkpoint(sd, model=m, row_sharded=["blocks.nothing"], world=2, rank=1)
+    assert "blocks.a+b.local.wq" in S.convert_checkpoint(sd, model=m, column_sharded=[r"re:blocks\..*"], world=2, rank=1)

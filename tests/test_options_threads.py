@@ -1,0 +1,80 @@
+"""CPU: the library's behaviour switches are an immutable snapshot per C-ABI call (include/pq_hip.h, pq_set_option) — concurrent host threads are defined —
+and the planner refuses a fused split-K plan whose grid does not fit the CUs the device reports (PQ_FAKE_CUS)."""
+import threading
+
+import pytest
+
+from protoquant_amd import _lib
+
+
+@pytest.fixture
+def L():
+    lib = _lib.lib()
+    yield lib
+    for n in ("PQ_FORCE_VARIANT", "PQ_FAKE_CUS", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_NO_SPLITK"):
+        _lib.set_option(n, "")
+
+
+def test_a_call_never_sees_a_mixture_of_two_option_sets(L):
+    """4096 x 6144 x 4096: under auto the dispatcher names the 256 x 256 tile WITH a tail split; under PQ_FORCE_VARIANT=generic "generic64".  The name is
+    built from two reads of the switches (variant choice, then the tail plan): unpinned, a flip between the reads yields "sp256_16x16x64" with no tail —
+    a result neither option set can produce.  One thread flips the switch 20 000 times while four threads ask."""
+    auto, forced = b"sp256_16x16x64 + sp128 tail (N)", b"generic64"
+    assert L.pq_gemm_variant_name(4096, 6144, 4096, 4096, 4096) == auto
+    stop = threading.Event()
+    seen, bad = set(), []
+
+    def ask():
+        while not stop.is_set():
+            n = L.pq_gemm_variant_name(4096, 6144, 4096, 4096, 4096)
+            seen.add(n)
+            if n not in (auto, forced):
+                bad.append(n)
+
+    ts = [threading.Thread(target=ask) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for i in range(20000):
+        assert L.pq_set_option(b"PQ_FORCE_VARIANT", b"generic" if i % 2 == 0 else b"") == 0
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:3]
+    assert seen == {auto, forced}
+
+
+def test_concurrent_setters_do_not_lose_each_others_switches(L):
+    """two threads set DIFFERENT switches concurrently (copy - modify - publish under the writers' mutex): both survive"""
+    def setter(name, val, n):
+        for _ in range(n):
+            assert L.pq_set_option(name, val) == 0
+    a = threading.Thread(target=setter, args=(b"PQ_FORCE_VARIANT", b"ring128", 3000))
+    b = threading.Thread(target=setter, args=(b"PQ_NO_SPLITK", b"1", 3000))
+    a.start(); b.start(); a.join(); b.join()
+    assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) == b"ring128_16x16x64"
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0          # PQ_NO_SPLITK survived the other thread's writes
+    assert L.pq_set_option(b"PQ_NOT_A_SWITCH", b"1") != 0 and b"unknown option" in L.pq_last_error()
+
+
+def _fsk_bytes(tiles, S):
+    return ((tiles * 4 * (4 if S == 4 else 2) + 255) // 256) * 256 + tiles * (S - 1) * 256 * 256 * 4
+
+
+def test_planner_refuses_fused_splitk_beyond_the_devices_cus(L):
+    """cfg-3 `down` (128 tiles x 2 slices = 256 workgroups) and the 70B `down` shard (64 x 4 = 256): planned on a 256-CU device; on a device that
+    reports fewer CUs (CU-masked / partitioned: PQ_FAKE_CUS) the in-kernel hand-over is refused — the single-pass tile resp. the two-pass split-K runs."""
+    L.pq_set_option(b"PQ_FAKE_CUS", b"256")
+    assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == _fsk_bytes(128, 2)
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == _fsk_bytes(64, 4)
+    L.pq_set_option(b"PQ_FAKE_CUS", b"255")
+    assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == 0                              # -> 128 x 256 tiles, one pass
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 4 * 4096 * 1024 * 4           # -> two-pass split-K, 4 slabs of the whole output
+    L.pq_set_option(b"PQ_FAKE_CUS", b"304")
+    assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == _fsk_bytes(128, 2)
+    # forced slice counts (experiments): the ticket form runs on any grid, the symmetric forms only when every workgroup can be resident
+    L.pq_set_option(b"PQ_FAKE_CUS", b"256")
+    L.pq_set_option(b"PQ_FSK", b"2")
+    assert L.pq_qlinear_workspace_bytes(4096, 4096, 4096) == _fsk_bytes(256, 2)
+    L.pq_set_option(b"PQ_FSK_SYMMETRIC", b"1")
+    assert L.pq_qlinear_workspace_bytes(4096, 4096, 4096) == 0
+    assert L.pq_qlinear_workspace_bytes(2048, 4096, 4096) == _fsk_bytes(128, 2)

@@ -20,6 +20,9 @@ for M, N, K, mode in SHAPES:
         xs = torch.rand(M, device="cuda", generator=g) * 0.1; ws = torch.rand(N, device="cuda", generator=g) * 0.01
         pool.append((a, xs, b, ws, pq.qlinear_s8(a, xs, b, ws, None, torch.bfloat16).clone()))
     _lib.set_option("PQ_FSK", mode)
+    _lib.set_option("PQ_FSK_SYMMETRIC", os.environ.get("FSK_STRESS_SYMMETRIC", ""))     # (the default form is the ticket form; tests/test_gpu_fsk_stress.py runs both in the gpu suite)
+    if _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0:
+        print(f"{M}x{N}x{K} PQ_FSK={mode or 'plan'}: refused by the planner (grid > CUs in the symmetric form)"); continue
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0, (M, N, K, mode)
     nbad = 0
     for i in range(REPS):

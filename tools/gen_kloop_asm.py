@@ -14,7 +14,8 @@ The tile body follows the HIP lambda `tile` of gemm_s8_fast.hip operation for op
 same DMA pieces in the same per-wave issue order, the same vmcnt counts), so the statement is entered after the HIP code's tile 0
 (first-half prologue) and its results are the HIP loop's bit for bit.
 
-usage: python tools/gen_kloop_asm.py [--check]     (--check: exit 1 if the committed .inc differs from what would be generated)
+usage: python tools/gen_kloop_asm.py [--check | --dev]     (--check: exit 1 if the committed .inc differs from what would be generated;
+       --dev: write only kloop_p3_asm_dev.inc — the timing-only ablation variants, untracked, included by dev builds: make ABLATION=1)
 """
 import os
 import sys
@@ -701,12 +702,15 @@ def render(vids, name, dev):
 def main():
     text, mixes = render([v for v in sorted(VARIANTS) if v in PRODUCT], "kloop_p3_asm", False)
     text_dev, mixes_dev = render([v for v in sorted(VARIANTS) if v not in PRODUCT], "kloop_p3_asm_dev", True)
-    if "--check" in sys.argv:
-        for path, want in ((OUT, text), (OUT_DEV, text_dev)):
-            cur = open(path).read() if os.path.exists(path) else ""
-            if cur != want:
-                print(f"{os.path.basename(path)} is stale: run python tools/gen_kloop_asm.py")
-                sys.exit(1)
+    if "--check" in sys.argv:              # the SHIPPED file only: kloop_p3_asm_dev.inc is not tracked (generated by `make ABLATION=1` / --dev)
+        cur = open(OUT).read() if os.path.exists(OUT) else ""
+        if cur != text:
+            print(f"{os.path.basename(OUT)} is stale: run python tools/gen_kloop_asm.py")
+            sys.exit(1)
+        return
+    if "--dev" in sys.argv:                # only the dev-only include (timing ablations), for `make ABLATION=1`
+        with open(OUT_DEV, "w") as f:
+            f.write(text_dev)
         return
     with open(OUT, "w") as f:
         f.write(text)
