@@ -469,6 +469,7 @@ def run_llama70b_shard(args):
     configuration, so down's input is quantised by plain K1), plus the lm_head shard (16032).  No collective runs (one GPU): the
     exchange is priced from the bytes with the xGMI link model of DESIGN.md section 6, and stated as modelled."""
     import protoquant_amd as pq
+    from protoquant_amd import _lib as L_
     from protoquant_amd.qtensor import QTensor
     dev = torch.device("cuda", 0)
     G, M, H, I, V, L = 8, args.tokens, 8192, 28672, 128256, args.layers if args.layers != 32 else 80
@@ -539,6 +540,45 @@ def run_llama70b_shard(args):
         del rl
     except Exception as e:      # an extra figure must never lose the main line
         print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
+    # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (two alternating weight sets; shards of 8 - 60 MB:
+    # Infinity-Cache-warm, so the sum is a little below the step, whose weights cycle through ~210 MB), with its share of the layer and — for the GEMMs —
+    # its fraction of the int8 peak: the per-shape account of the distance to 0.50
+    per_shape = None
+    try:
+        def ev_graph(fn, n=8):
+            g = graph_of(fn, n)
+            g.replay(); torch.cuda.synchronize()
+            v = []
+            for _ in range(7):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); g.replay(); b.record(); b.synchronize()
+                v.append(a.elapsed_time(b) * 1e3 / n)
+            return sorted(v)[len(v) // 2]
+        qn = pq.rmsnorm_quantize(x_h, norm_w, 1e-5)
+        qh = pq.quantize(x_h)
+        qi = pq.quantize(x_i)
+        items = [("rmsnorm -> int8 (input of qkv; again for gate+up)", None, lambda l: pq.rmsnorm_quantize(x_h, norm_w, 1e-5), 2),
+                 ("fused qkv shard", (M, n_qkv, H), lambda l: layers[l][0](qn), 1),
+                 ("K1 of o's input (replicated attention output)", None, lambda l: pq.quantize(x_h), 1),
+                 ("o shard", (M, n_o, H), lambda l: layers[l][1](qh), 1),
+                 ("fused gate+up shard", (M, n_gu, H), lambda l: layers[l][2](qn), 1),
+                 ("K1 of down's input (the GATHERED silu(g)*u, 4096 x 28672)", None, lambda l: pq.quantize(x_i), 1),
+                 ("down shard", (M, n_down, I), lambda l: layers[l][3](qi), 1)]
+        per_shape, tot = [], 0.0
+        for name, shp, fn, mult in items:
+            us = ev_graph(lambda: (fn(0), fn(1)), 4) / 2
+            tot += us * mult
+            d = {"kernel": name, "us": round(us, 1), "per_layer": mult}
+            if shp is not None:
+                d["shape"] = "x".join(str(v) for v in shp)
+                d["frac_of_int8_peak"] = round(2.0 * shp[0] * shp[1] * shp[2] / us / 1e6 / PEAK_INT8_TOPS, 3)
+                d["dispatch"] = L_.lib().pq_gemm_variant_name(shp[0], shp[1], shp[2], shp[2], shp[2]).decode() + (" + workspace" if L_.lib().pq_qlinear_workspace_bytes(*shp) else "")
+            per_shape.append(d)
+        for d in per_shape:
+            d["share_of_layer"] = round(d["us"] * d["per_layer"] / tot, 3)
+        per_shape.append({"sum_per_layer_us": round(tot, 1), "step_per_layer_us": round(dt / L * 1e6, 1)})
+    except Exception as e:
+        print(f"[bench] per-shape leg failed: {e}", file=sys.stderr)
     # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
     gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
     t_gather = gathered * (G - 1) / G / (7 * 153e9)
@@ -548,7 +588,7 @@ def run_llama70b_shard(args):
                       "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
                                              f"4096x{n_o}x8192 (o), 4096x{n_gu}x8192 (fused gate+up), 4096x{n_down}x28672 (down), 4096x{n_head}x8192 (lm_head) (BASELINE configs[4])",
                                  "int8_ops_per_rank": ops, "gathered_bytes_per_pass": gathered,
-                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing,
+                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing, "per_shape": per_shape,
                                  "model": "all-gather after dequant of every linear's bf16 output; a rank receives 7/8 of it over 7 xGMI links x 153 GB/s (fully connected, direct); NOT measured"},
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,

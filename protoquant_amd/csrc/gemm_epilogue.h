@@ -83,12 +83,12 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
                                                  uint8_t* smem, uint32_t sw_off, uint8_t* y_blk, int64_t ldy_bytes, int lane) {
     using O = typename OutElem<OUT>::type;
     constexpr int OB = (int)sizeof(O);
-    constexpr int RBY = PT_PASS * 16 * OB;                // staged row bytes: 128, 256 or 512
+    constexpr int RBY = PT_PASS * 16 * OB;                // staged row bytes: 64 (two half-precision column tiles: the 64 x 64 ring tile), 128, 256 or 512
     constexpr int CPR = RBY / 16;                         // 16-byte chunks per staged row
     constexpr int KM = (CPR < 16 ? CPR : 16) - 1;         // swizzle key mask
     constexpr int RPI = 64 / CPR;                         // rows per ds_read_b128 / global store instruction: 8, 4 or 2
     constexpr int CSH = (OB == 2) ? 1 : 2;                // chunk of column tile p (inside a pass) = (p << CSH) | b
-    static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && (RBY == 128 || RBY == 256 || RBY == 512), "epilogue pass shape");
+    static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && (RBY == 64 || RBY == 128 || RBY == 256 || RBY == 512), "epilogue pass shape");
     const int dcol = lane & 15, q = lane >> 4;
     const int b = (OB == 2) ? (q >> 1) : q;
     const uint32_t low = (OB == 2) ? (uint32_t)(q & 1) * 8u : 0u;

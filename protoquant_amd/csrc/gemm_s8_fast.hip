@@ -31,63 +31,13 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "gemm_epilogue.h"
+#include "gemm_tile_common.h"
 #include "kloop_p3_asm.inc"   // generated: tools/gen_kloop_asm.py
 
 namespace pq {
 
-constexpr int FT = 256;          // tile edge (both m and n)
-constexpr int FBK = 128;         // K bytes per tile step
-
-// s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
-constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | 0x70 | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
-// vmcnt(n) for a run-time n (prologue only): the builtin wants a literal
-__device__ __forceinline__ void wait_vmcnt_lgkm0(int n) {
-    switch (n) {
-#define PQ_W(k) case k: __builtin_amdgcn_s_waitcnt(waitcnt_imm(k, 0)); break;
-        PQ_W(0) PQ_W(1) PQ_W(2) PQ_W(3) PQ_W(4) PQ_W(5) PQ_W(6) PQ_W(7) PQ_W(8) PQ_W(9) PQ_W(10) PQ_W(11) PQ_W(12) PQ_W(13) PQ_W(14) PQ_W(15)
-        PQ_W(16) PQ_W(17) PQ_W(18) PQ_W(19) PQ_W(20) PQ_W(21) PQ_W(22) PQ_W(23) PQ_W(24) PQ_W(25) PQ_W(26) PQ_W(27) PQ_W(28) PQ_W(29) PQ_W(30) PQ_W(31)
-#undef PQ_W
-        default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0)); break;
-    }
-}
-
-typedef const void __attribute__((address_space(1)))* gptr_t;
-typedef void __attribute__((address_space(3)))* lptr_t;
-
-// LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form: no 64-bit VALU address math beside the MFMAs.
-// base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written in the same statement that reads it
-// and NOT restored: these kernels contain no compiler-generated user of M0 (every LDS-DMA goes through these helpers;
-// `make asm` + grep m0 confirms) — round 1 saved and restored it around every piece, 16 extra SALU per K-tile per wave.
-// hipcc does not count this load: the K-loop waits with explicit vmcnt.
-__device__ __forceinline__ void glds16_sbase(const int8_t* base, uint32_t voff, uint32_t lds_addr) {
-    // (cache-policy bits on this load — sc1 / sc0, which bypass the vector L1 — measured within 0.2 % of none on every tile kind:
-    // profiles/r02_ab_experiments.txt)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
-}
-// the same with a per-lane 64-bit source address (scale vectors in the prologue)
-__device__ __forceinline__ void glds16_vaddr(const void* src, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(src), "s"(lds_addr) : "memory");
-}
-
-// XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 // fused split-K workspace: bytes of the two per-tile counter arrays in front of the slabs
 __host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles, int kslices) { return ((size_t)ntiles * 4 * (kslices == 4 ? 4 : 2) + 255) & ~(size_t)255; }   // ticket form: {ticket, ready} per tile; symmetric forms: one flag per slice
-
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
 
 // TM: rows (m) of the output tile, 256 or 128.  TM = 128 halves the Q (activation) side — 16 rows per wave-half, one
 // 16x16 MFMA tile — for problems whose 256x256 grid would leave most CUs idle; it needs 48 KiB of DMA per
@@ -132,6 +82,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     constexpr bool DBG = ABL != 0;
     constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
     constexpr bool no_vmwait = ABL & 32, no_barrier = ABL & 64;   // timing-only: results are wrong
+    constexpr bool half_epi = ABL & 2048;                         // timing-only (round 4): the epilogue of ONE column half only — 16 of the 32 MB: a bound on what an early epilogue of half the accumulators can return
     constexpr int SHAPE = 16;                                     // v_mfma_i32_16x16x64_i8
     (void)dbg;
     // dev builds: every wave stamps the chip-wide 100 MHz counter (s_memrealtime) and its shader-cycle counter (s_memtime)
@@ -163,7 +114,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
 
     static_assert(!LC || (TM == 128 && TN == 256), "loader / consumer split: 128 x 256 tile only");
     static_assert(!P3 || (TM == 256 && TN == 256 && !LC), "split rings: 256 x 256 tile only");
-    static_assert(ASMV == 0 || (P3 && (ABL == 0 || ABL == 1024)), "asm K-loop: split-ring tile only (dev builds: with stamps)");
+    static_assert(ASMV == 0 || (P3 && (ABL & ~(1024 | 8 | 2048)) == 0), "asm K-loop: split-ring tile only (dev builds: with stamps, and the epilogue ablations)");
     static_assert(FSK == 0 || (P3 && ASMV != 0 && ABL == 0 && OUT != OUT_I32), "fused split-K: the asm split-ring kernel with a dequantising epilogue");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -511,6 +462,19 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             e0 = e0 + 3 < slim ? e0 : (slim >= 4 ? slim - 4 : 0);
             const float* ssrc = (w == 0 ? epi.a_scale : epi.b_scale) + e0;
             const uint32_t do_scales = (uint32_t)__builtin_amdgcn_readfirstlane((int)(OUT != OUT_I32 && scales_ok && w < 2));   // ("s" operands must be provably uniform)
+            if constexpr (ASMV == 11) {      // dev builds, timing only: the Q operand straight from L2 — the per-lane offsets of the MFMA operand layout (16 rows x 64 B per load)
+                uint32_t offQd[2][QPW];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int jj = 0; jj < QPW; ++jj) {
+                        int r = wq * WM + h * (WM / 2) + jj * 16 + (lane & 15);
+                        r = m0 + r < M ? r : M - 1 - m0;
+                        offQd[h][jj] = (uint32_t)r * (uint32_t)ldx + (uint32_t)(lane >> 4) * 16u;
+                    }
+                kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQd, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
+                                   0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
+            } else
             kloop_p3_asm<FSK != 0 ? 4 : ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
                                0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
             if constexpr (FSK == 1) {
@@ -662,6 +626,8 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
         else if (kslice == 1) epilogue(h0, h1);
         else if (kslice == 2) epilogue(h1, h0);
         else epilogue(h1, h1);
+    } else if constexpr (half_epi) {
+        epilogue(h0, all);
     } else {
         epilogue(all, all);
     }
@@ -931,10 +897,14 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         if (opt().sp256_p3 && gemm_debug_flags() == 1024) {      // stamps only, around an asm K-loop variant
             switch (K >= 5 * FBK ? opt().sp256_asm : 0) {
 #define PQ_ASMS(n) case n: gemm_s8_sp256<OUT, 1024, TM, TN, false, true, n><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1024, g_stamps, 1); return;
-                PQ_ASMS(1) PQ_ASMS(2) PQ_ASMS(3) PQ_ASMS(6) PQ_ASMS(7) PQ_ASMS(8) PQ_ASMS(9)
+                PQ_ASMS(1) PQ_ASMS(2) PQ_ASMS(3) PQ_ASMS(6) PQ_ASMS(7) PQ_ASMS(8) PQ_ASMS(9) PQ_ASMS(10) PQ_ASMS(11)
 #undef PQ_ASMS
                 default: break;
             }
+        }
+        if (opt().sp256_p3 && K >= 5 * FBK && opt().sp256_asm == 1) {      // round 4: the product asm loop + stamps with NO epilogue (1032) / HALF the epilogue (3072): timing only
+            if (gemm_debug_flags() == 1032) { gemm_s8_sp256<OUT, 1032, TM, TN, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1032, g_stamps, 1); return; }
+            if (gemm_debug_flags() == 3072) { gemm_s8_sp256<OUT, 3072, TM, TN, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 3072, g_stamps, 1); return; }
         }
         if (opt().sp256_p3) {
             switch (gemm_debug_flags()) {

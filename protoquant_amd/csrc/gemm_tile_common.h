@@ -1,0 +1,60 @@
+// gemm_tile_common.h — helpers shared by the tiled GEMM translation units (gemm_s8_fast.hip, gemm_s8_ring.hip): s_waitcnt immediates,
+// the LDS-DMA forms, the XCD-aware block remap, a compile-time loop.
+#pragma once
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+
+namespace pq {
+
+constexpr int FT = 256;          // tile edge (both m and n)
+constexpr int FBK = 128;         // K bytes per tile step
+
+// s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | 0x70 | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+// vmcnt(n) for a run-time n (prologue only): the builtin wants a literal
+__device__ __forceinline__ void wait_vmcnt_lgkm0(int n) {
+    switch (n) {
+#define PQ_W(k) case k: __builtin_amdgcn_s_waitcnt(waitcnt_imm(k, 0)); break;
+        PQ_W(0) PQ_W(1) PQ_W(2) PQ_W(3) PQ_W(4) PQ_W(5) PQ_W(6) PQ_W(7) PQ_W(8) PQ_W(9) PQ_W(10) PQ_W(11) PQ_W(12) PQ_W(13) PQ_W(14) PQ_W(15)
+        PQ_W(16) PQ_W(17) PQ_W(18) PQ_W(19) PQ_W(20) PQ_W(21) PQ_W(22) PQ_W(23) PQ_W(24) PQ_W(25) PQ_W(26) PQ_W(27) PQ_W(28) PQ_W(29) PQ_W(30) PQ_W(31)
+#undef PQ_W
+        default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0)); break;
+    }
+}
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+// LDS-DMA in its SGPR-base + 32-bit-VGPR-offset form: no 64-bit VALU address math beside the MFMAs.
+// base must be wave-uniform, lds_addr a wave-uniform LDS byte address.  M0 is written in the same statement that reads it
+// and NOT restored: these kernels contain no compiler-generated user of M0 (every LDS-DMA goes through these helpers;
+// `make asm` + grep m0 confirms) — round 1 saved and restored it around every piece, 16 extra SALU per K-tile per wave.
+// hipcc does not count this load: the K-loop waits with explicit vmcnt.
+__device__ __forceinline__ void glds16_sbase(const int8_t* base, uint32_t voff, uint32_t lds_addr) {
+    // (cache-policy bits on this load — sc1 / sc0, which bypass the vector L1 — measured within 0.2 % of none on every tile kind:
+    // profiles/r02_ab_experiments.txt)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+// the same with a per-lane 64-bit source address (scale vectors in the prologue)
+__device__ __forceinline__ void glds16_vaddr(const void* src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_addr) : "memory");
+}
+
+// XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+}  // namespace pq

@@ -19,6 +19,7 @@ template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, i
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int OUT> void launch_gemm_ringt(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
@@ -49,7 +50,7 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY, V_RING64X128, V_RING64X64 };
 
 Variant parse_variant(const char* e) {
     if (!e || !*e) return V_AUTO;
@@ -59,6 +60,8 @@ Variant parse_variant(const char* e) {
     if (!strcmp(e, "sp128x128")) return V_SP128X128;
     if (!strcmp(e, "ring128")) return V_RING128;
     if (!strcmp(e, "skinny")) return V_SKINNY;
+    if (!strcmp(e, "ring64x128")) return V_RING64X128;
+    if (!strcmp(e, "ring64x64")) return V_RING64X64;
     return V_AUTO;
 }
 
@@ -73,7 +76,7 @@ thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by
 thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FAKE_CUS", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
@@ -85,6 +88,8 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_FSK")) o.fsk = set ? iv : -1;
     else if (!strcmp(name, "PQ_FSK_SYMMETRIC")) o.fsk_symmetric = set && *value == '1';
     else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
+    else if (!strcmp(name, "PQ_NO_MIDM")) o.no_midm = set;
+    else if (!strcmp(name, "PQ_MIDM_CT")) o.midm_ct = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) o.rms_wave_max = !set || iv < 0 ? 256 : (iv > 512 ? 512 : iv);
     else if (!strcmp(name, "PQ_SILU_TPR")) o.silu_tpr = set && !strcmp(value, "256") ? 256 : 0;
     else if (!strcmp(name, "PQ_SP128_LC")) o.sp128_lc = !set || iv < 0 || iv > 2 ? 1 : iv;
@@ -173,7 +178,19 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // even 128-row tiles fill at most half the chip: 128 x 128 tiles from a 4-deep DMA ring (gemm_s8_ring128; latency-bound
     // on operand ingest, ~2/3 of the 128 x 256 tile's rate per CU, but twice the blocks and no slab traffic).  Measured:
     // k/v 4096x1024x4096 31 -> 24 us, 70B q/o shard 47 (split-K) -> 40 us, 70B down shard 124 (split-K) -> 119 us.
-    if (t128 <= 128 && t128sq > t128) return V_RING128;
+    if (t128 <= 128 && t128sq > t128) {
+        // 64 < M <= 512 (gemm_s8_ring.hip): when the 128 x 128 ring tiles fill well under the chip, SMALLER tiles on every CU — the regime is bound by the L2 -> CU path and
+        // the LDS (a small tile moves 3 bytes through the LDS per byte it ingests), and a K split over workgroups costs as much hand-over latency as it saves on launches
+        // this short.  Rounds of the 256 CUs x the measured time of one tile relative to the 128 x 128 ring tile (K = 4096: 14.0 / 13.4 / 9.2 us; profiles/r04_midm.txt);
+        // PQ_NO_MIDM=1 restores the round-3 dispatch.
+        if (M <= 512 && !options().no_midm && options().force_splitk <= 1 && options().fsk <= 1) {      // (a forced slice count — experiments, tests — means the split-K forms)
+            auto rounds = [](int64_t tiles) { return (double)((tiles + 255) / 256); };
+            const double c128 = rounds(t128sq) * 1.00, c64x128 = rounds(((M + 63) / 64) * ((N + 127) / 128)) * 0.95, c64x64 = rounds(((M + 63) / 64) * ((N + 63) / 64)) * 0.66;
+            if (c64x64 < c128 && c64x64 <= c64x128) return V_RING64X64;
+            if (c64x128 < c128) return V_RING64X128;
+        }
+        return V_RING128;
+    }
     if (t256 <= 160 && t128 > t256 && t128 <= 256) return V_SP128_16;
     return V_SP256_16;
 }
@@ -187,6 +204,8 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
     else if (v == V_SP128X128) pq::launch_gemm_fast<OUT, 128, 128>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_SKINNY) pq::launch_gemm_skinny<OUT>(a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_RING64X128) pq::launch_gemm_ringt<OUT>(0, a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_RING64X64) pq::launch_gemm_ringt<OUT>(1, a, lda, b, ldb, epi, M, N, K, st);
     else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
 }
 
@@ -414,6 +433,10 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
 
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     CallScope scope_;
+    {   // (alignment of the operands is unknown here: assume the fast path, as pq_gemm_variant_name does)
+        const Variant v = pick_variant(reinterpret_cast<const int8_t*>(16), K, reinterpret_cast<const int8_t*>(16), K, M, N, K);
+        if (v == V_RING64X128 || v == V_RING64X64) return 0;      // the mid-M tiles run single-pass
+    }
     if (const int f = fsk_plan(M, N, K)) return pq::fsk_workspace_bytes(M, N, f);
     int tm = 256;
     const int s = splitk_plan(M, N, K, &tm);
@@ -558,6 +581,8 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
         case V_SP128X128: return "sp128x128_16x16x64";
         case V_RING128: return "ring128_16x16x64";
         case V_SKINNY: return "skinny_16x16x64";
+        case V_RING64X128: return "ring64x128_16x16x64";
+        case V_RING64X64: return "ring64x64_16x16x64";
         default: return "generic64";
     }
 }

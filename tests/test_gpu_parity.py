@@ -37,7 +37,7 @@ def test_golden_quantize(pq, golden):
     same_f(pq.dequantize(qc), g["x_coldeq"], g["code"], "x_coldeq")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
 def test_golden_gemm_and_qlinear(pq, golden, variant, pq_opt):
     g = golden
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -70,7 +70,7 @@ SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), 
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
 def test_int_gemm_exact_full_range(pq, M, N, K, variant, pq_opt):
     """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -82,7 +82,7 @@ def test_int_gemm_exact_full_range(pq, M, N, K, variant, pq_opt):
     same(got, want, f"acc {M}x{N}x{K} {variant}")
 
 
-@pytest.mark.parametrize("variant", ["sp256_16", "sp128_16", "sp128x128", "ring128", "generic"])
+@pytest.mark.parametrize("variant", ["sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "generic"])
 def test_gemm_identity_asymmetric(pq, variant, pq_opt):
     """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
     pq_opt("PQ_FORCE_VARIANT", variant)
@@ -168,7 +168,7 @@ def test_quant_strided_and_unaligned(pq):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
                                               (512, 1024, 512, 0, False)])
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
 def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, pq_opt):
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M + N + K + code)
@@ -208,8 +208,12 @@ def test_qlinear_unaligned_scales_and_output(pq):
                                               (200, 2048, 14336, 1, False)])
 def test_splitk_bit_identical(pq, M, N, K, code, bias, pq_opt):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
-    == the single-pass kernel (PQ_NO_SPLITK)."""
+    == the single-pass kernel (PQ_NO_SPLITK).  (M <= 512: since round 4 the dispatcher prefers the single-pass 64-row ring tiles there; PQ_NO_MIDM=1 keeps
+    the two-pass path covered at those shapes too.)"""
     from protoquant_amd import _lib
+    if M <= 512:
+        assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0 and _lib.lib().pq_gemm_variant_name(M, N, K, K, K).startswith(b"ring64")
+        pq_opt("PQ_NO_MIDM", "1")
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0, "shape should be planned as split-K"
     rng = np.random.default_rng(M + N + K)
     a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
@@ -383,7 +387,7 @@ def test_split_rings_bit_identical(pq, M, N, K, code, bias, pq_opt):
 def test_splitk_workspace_too_small_is_an_error(pq):
     from protoquant_amd import _lib
     L = _lib.lib()
-    M, N, K = 512, 1024, 8192
+    M, N, K = 1024, 1024, 8192          # (a quarter-filled grid with a long K: planned as split-K; M <= 512 runs the single-pass 64-row ring tiles since round 4)
     need = L.pq_qlinear_workspace_bytes(M, N, K)
     assert need > 0
     a = torch.zeros((M, K), dtype=torch.int8, device="cuda"); b = torch.zeros((N, K), dtype=torch.int8, device="cuda")
@@ -1106,3 +1110,33 @@ def test_errors_are_loud(pq):
     L = _lib.lib()
     st = L.pq_quant_rowwise(None, 0, 4, 4, 2, None, 4, None, None)
     assert st == 1 and b"pq_quant_rowwise" in L.pq_last_error()
+
+
+@pytest.mark.parametrize("M,N,K,want", [(65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
+                                        (384, 4096, 14336, "ring64x128"), (512, 4096, 4096, "ring64x128"), (512, 4096, 14336, "ring64x128"), (500, 4000, 1152, "ring64x128"),
+                                        (128, 28672, 4096, "ring128"), (512, 28672, 4096, "sp256")])
+def test_mid_m_regime_exact(pq, M, N, K, want, pq_opt):
+    """64 < M <= 512 (round-3 verdict item 4): the 64-row ring tiles of gemm_s8_ring.hip, chosen by the dispatcher when the 128 x 128 ring tiles would fill well
+    under the chip.  Full-range int8 operands: int32 accumulator == an exact float64 matmul, y == the QSPEC epilogue (bias, every output dtype), ==
+    the round-3 dispatch (PQ_NO_MIDM=1) bit for bit, ragged M / N included."""
+    from protoquant_amd import _lib
+    name = _lib.lib().pq_gemm_variant_name(M, N, K, K, K).decode()
+    assert name.startswith(want), name
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0 or not want.startswith("ring64")
+    rng = np.random.default_rng(M * 31 + N * 7 + K)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    same(pq.int_mm(ta, tb), acc, f"acc [{name}]")
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    txs, tws = torch.from_numpy(xs).cuda(), torch.from_numpy(ws).cuda()
+    for code in (0, 1, 2):
+        bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), code) if code != 1 else None
+        y = pq.qlinear_s8(ta, txs, tb, tws, to_gpu(bv, code) if bv is not None else None, TD[code])
+        same(y, Q.epilogue(acc, xs, ws, bv, code), f"y dt{code} [{name}]")
+        if code == 0:
+            pq_opt("PQ_NO_MIDM", "1")
+            assert not _lib.lib().pq_gemm_variant_name(M, N, K, K, K).decode().startswith("ring64")
+            y3 = pq.qlinear_s8(ta, txs, tb, tws, to_gpu(bv, code), TD[code])
+            pq_opt("PQ_NO_MIDM", "")
+            assert torch.equal(y.view(torch.int16), y3.view(torch.int16)), "mid-M tiles vs the round-3 dispatch"

@@ -7,6 +7,8 @@ import numpy as np
 import torch
 import protoquant_amd as pq
 from protoquant_amd import _lib as _pqlib  # noqa: E402
+if os.environ.get("PQ_ABL_LIB"):          # a dev build kept beside the product library (make ABLATION=1, copied to tools/libpq_hip_abl.so)
+    _pqlib.LIB_PATH = os.path.abspath(os.environ["PQ_ABL_LIB"])
 from tools.quick_bench import timeit
 M = N = K = 4096
 if os.environ.get("PQ_ABL_SHAPE"):          # e.g. PQ_ABL_SHAPE=4096x28672x4096 (multi-round grids: stamps are per hardware block id)
@@ -32,7 +34,7 @@ for flags in [int(a) for a in sys.argv[1:]] or [0, 1024, 8, 1, 2, 3, 4, 12, 32, 
     os.environ["PQ_GEMM_DBG"] = str(flags)
     stamps.zero_()
     med, mn = timeit(lambda: pq.qlinear_s8(xq, xs, wq, ws, None, torch.bfloat16, out=out), iters=100)
-    names = [n for b, n in ((1, "noDMA"), (2, "noLDS"), (4, "noMFMA"), (8, "noEPI"), (32, "noVMWAIT"), (64, "noBARRIER"), (1024, "stamps")) if flags & b]
+    names = [n for b, n in ((1, "noDMA"), (2, "noLDS"), (4, "noMFMA"), (8, "noEPI"), (32, "noVMWAIT"), (64, "noBARRIER"), (2048, "halfEPI"), (1024, "stamps")) if flags & b]
     torch.cuda.synchronize()
     line = f"flags={flags:4d} {'+'.join(names) or 'product':22s} median {med:6.1f} us  min {mn:6.1f} us"
     if flags:

@@ -32,8 +32,10 @@ GP, GQ = "s[88:89]", "s[90:91]"     # pinned SGPR pairs: weight K cursor, activa
 class Emitter:
     """Instruction list with byte offsets (8-byte alignment of 8-byte encodings) and an in-order model of the LDS-read queue."""
 
-    def __init__(self, align8, nowait, nobar, nodma=False, nolds=False):
+    def __init__(self, align8, nowait, nobar, nodma=False, nolds=False, rdrop=False, qdirect=False):
         self.nodma, self.nolds = nodma, nolds           # timing-only ablations: drop the LDS-DMA / the fragment reads
+        self.rdrop, self.qdirect = rdrop, qdirect       # timing-only (round 4): every third fragment read dropped / the Q operand straight from L2
+        self.nreads = 0
         self.lines = []
         self.off = 0            # bytes since the statement's .p2align 3
         self.align8 = align8
@@ -66,10 +68,17 @@ class Emitter:
 
     def ds_read(self, dst, base, imm):
         assert 0 <= imm < 65536, imm
-        if self.nolds:
+        self.nreads += 1
+        if self.nolds or (self.rdrop and self.nreads % 3 == 0):
             self.fifo.append(dst)          # (keeps the queue model, and with it the counted waits, as in the real loop)
             return
         self.raw(f"ds_read_b128 %[{dst}], %[{base}]" + (f" offset:{imm}" if imm else ""), 8, "ds_read")
+        self.fifo.append(dst)
+
+    def gload(self, dst, voff, sbase, imm):
+        """timing-only (qdirect): a Q fragment straight from L2 into its registers — 16 rows x 64 B per instruction, the MFMA operand layout"""
+        assert -4096 <= imm < 4096, imm
+        self.raw(f"global_load_dwordx4 %[{dst}], %[{voff}], {sbase}" + (f" offset:{imm}" if imm else ""), 8, "gload")
         self.fifo.append(dst)
 
     def need(self, regs):
@@ -157,8 +166,12 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
         fill.setdefault(idx, []).append(fn)
 
     rs = rstride                          # fragment reads in every rs-th MFMA shadow of their quadrant
+    goff_r = (t - 5) * 128 if (ptr == "imm" and flavour == "full") else 0      # (qdirect: the Q cursor runs two tiles ahead of the tile being multiplied)
     for it in range(4):                   # q0 shadows: Q1[kt] -> fQb
         j, ks = it % 2, it // 2
+        if E.qdirect:
+            add(it * rs, lambda j=j, ks=ks: E.gload(f"qb{j}{ks}", f"oq1{j}", GQ, goff_r - 256 + ks * 64))
+            continue
         add(it * rs, lambda j=j, ks=ks: E.ds_read(f"qb{j}{ks}", *q_addr(qs, 1, j, ks)))
     for it in range(8):                   # q1 shadows: P1[kt] -> fPb
         i, ks = it % 4, it // 4
@@ -169,6 +182,9 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
             add(32 + it * rs, lambda i=i, ks=ks: E.ds_read(f"pa{i}{ks}", *p_addr(psn, 0, i, ks)))
         for it in range(4):               # q3 shadows: Q0[kt+1] -> fQa
             j, ks = it % 2, it // 2
+            if E.qdirect:
+                add(48 + it * rs, lambda j=j, ks=ks: E.gload(f"qa{j}{ks}", f"oq0{j}", GQ, goff_r - 128 + ks * 64))
+                continue
             add(48 + it * rs, lambda j=j, ks=ks: E.ds_read(f"qa{j}{ks}", *q_addr(qsn, 0, j, ks)))
 
     goff = (t - 5) * 128 if (ptr == "imm" and flavour == "full") else 0
@@ -185,8 +201,9 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
                 nxt = min(idx + 1, 63)
                 if g < 4:
                     h, jj = g // 2, g % 2
-                    add(idx, lambda h=h, jj=jj: E.dma_m0(QBASE + qs * Q_SLOT + h * HALF + jj * KB - goff))
-                    add(nxt, lambda h=h, jj=jj: E.dma_load(f"oq{h}{jj}", GQ + osfx))
+                    if not E.qdirect:          # (qdirect: no Q side in the LDS at all)
+                        add(idx, lambda h=h, jj=jj: E.dma_m0(QBASE + qs * Q_SLOT + h * HALF + jj * KB - goff))
+                        add(nxt, lambda h=h, jj=jj: E.dma_load(f"oq{h}{jj}", GQ + osfx))
                     if g == 3 and (ptr == "bump" or flavour == "q"):
                         add(nxt, lambda: E.add64(GQ, 128))
                     if g == 3 and flavour == "q":
@@ -257,9 +274,9 @@ DMA_PLANS = {
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
 def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False, snake=False,
-      pinacc=False):
+      pinacc=False, rdrop=False, qdirect=False):
     return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio, nodma=nodma, nolds=nolds,
-                nowalk=nowalk, snake=snake, pinacc=pinacc)
+                nowalk=nowalk, snake=snake, pinacc=pinacc, rdrop=rdrop, qdirect=qdirect)
 
 
 VARIANTS = {
@@ -275,6 +292,13 @@ VARIANTS = {
     7: V("spread", nolds=True),                    # no fragment reads (the MFMAs run on whatever the registers hold)
     8: V("spread", nodma=True, nolds=True),        # neither: the bare MFMA stream with the loop's waits and barriers
     9: V("spread", nowalk=True),                   # the K cursors never leave the first ring turn: every DMA piece is an L2 hit (no fabric traffic), everything else as in 1
+    # timing only (wrong results), round 4 — the bounds of the round-3 verdict's structural experiments (ii) and (iii):
+    10: V("spread", rdrop=True),                   # every third fragment read dropped: 128 instead of 192 KiB of LDS reads per K-tile per CU — the read volume of a 4-wave
+                                                   # layout with 128 x 128 wave tiles, WITHOUT its cost (one wave per SIMD: nothing covers a wait): an upper bound of (ii)
+    11: V("spread", nowait=True, nobar=True, qdirect=True),   # the activation (Q) operand straight from L2 into the fragment registers (global_load_dwordx4, 16 rows x 64 B per
+                                                   # instruction): no Q-side LDS-DMA (-32 KiB), no Q-side fragment reads (-64 KiB), +64 KiB of L2 reads per K-tile per CU; no waits
+                                                   # at all (compare with 3, the product stream without waits): an upper bound of (iii), whose real form would also need the
+                                                   # loads two K-tiles ahead in registers it does not have
     # (tailprio=0 / 1 — one wave of every SIMD pair takes the matrix pipe behind the last barrier so that its epilogue runs beside the partner's MFMAs — was
     # built and measured: +-0.1 % on every shape, profiles/r03_ab_asm_kloop.txt run 4; the generator keeps the option, the library does not instantiate it)
 }
@@ -301,7 +325,7 @@ def gen_loop(E, tag, plan, cfg):
 
 def gen_variant(vid):
     cfg = VARIANTS[vid]
-    E = Emitter(cfg["align8"], cfg["nowait"], cfg["nobar"], cfg["nodma"], cfg["nolds"])
+    E = Emitter(cfg["align8"], cfg["nowait"], cfg["nobar"], cfg["nodma"], cfg["nolds"], cfg["rdrop"], cfg["qdirect"])
     E.lines.append(".p2align 3")
     E.raw("s_waitcnt lgkmcnt(0)", 4, "s_waitcnt")      # the fragment reads of tile 1 issued by the HIP code
     E.salu("s_sub_u32 %[cnt], %[cnt], 1")              # cnt = number of full tiles (NT - 4 >= 1): zero-based countdown
