@@ -180,6 +180,20 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     }
     const int8_t* gP = W + (int64_t)n0 * ldw + (int64_t)kslice * Ks;   // uniform; advanced by FBK per staged K-tile
     const int8_t* gQ = X + (int64_t)m0 * ldx + (int64_t)kslice * Ks;
+    // K walk of the loader / consumer form (round 4; `dbg` carries the chunk length in K-tiles for that form, 0 = the plain walk): the up-to-4 workgroups of a band
+    // that stream one weight panel (neighbours on one XCD, started together) walk each chunk of K-tiles from different starting points and wrap inside the chunk —
+    // gemm_s8_ring.hip, "K ROTATION in chunks".  Integer sums: same bits.
+    const bool rot_on = LC && !P3 && dbg > 0;
+    const int rot_ct = rot_on ? dbg : (1 << 30);
+    const int8_t* const gP0 = gP;
+    const int8_t* const gQ0 = gQ;
+    auto rot_of = [&](int len) { return rot_on ? (int)(((int64_t)(tin % gm) * len) / gm) : 0; };
+    int cbase = 0, clen = rot_ct < Ks / FBK ? rot_ct : Ks / FBK;
+    int cpos = rot_of(clen), cleft = clen;
+    if constexpr (LC && !P3) {
+        const int koff0 = __builtin_amdgcn_readfirstlane(cpos * FBK);
+        gP += koff0; gQ += koff0;
+    }
     const int piece_off = w * PPW * 1024;       // this wave's PPW pieces of a P half-tile
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;   // LDS byte address of the array
 
@@ -235,7 +249,21 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             constexpr int h = isQ ? (g - PPW) / QPW : (g >= PPW ? 1 : 0);
             constexpr int jj = isQ ? (g - PPW) % QPW : (g < PPW ? g : g - PPW - 2 * QPW);
             dma_piece(std::integral_constant<bool, isQ>{}, std::integral_constant<int, h>{}, std::integral_constant<int, jj>{}, isQ ? q_off(buf) : p_off(buf));
-            if constexpr (g == NDMA - 1) { gP += FBK; gQ += FBK; }
+            if constexpr (g == NDMA - 1) {
+                if constexpr (LC && !P3) {
+                    if (++cpos == clen) cpos = 0;
+                    if (--cleft == 0) {
+                        cbase += clen;
+                        clen = Ks / FBK - cbase < rot_ct ? Ks / FBK - cbase : rot_ct;
+                        cleft = clen;
+                        cpos = clen > 0 ? rot_of(clen) : 0;
+                    }
+                    const int koff = __builtin_amdgcn_readfirstlane((cbase + cpos) * FBK);
+                    gP = gP0 + koff; gQ = gQ0 + koff;
+                } else {
+                    gP += FBK; gQ += FBK;
+                }
+            }
         }
     };
     // P3 steady state: the Q side of tile kt+2 FIRST (it is needed one K-tile earlier: the mid-tile wait may leave the P pieces behind
@@ -888,7 +916,9 @@ void launch_gemm_fast(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb
         }
 #endif
         if (opt().sp128_lc) {
-            gemm_s8_sp256<OUT, 0, TM, TN, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, 1);
+            // K rotation of the loaders (`dbg` = K-tiles per chunk): for weight streams that matter (>= 6 MiB: profiles/r04_rotation.txt), chunks of 8 K-tiles
+            const int ct = (opt().ring_rot && N * K >= (6 << 20)) ? (opt().ring_rot > 1 ? opt().ring_rot : rot_chunk_ktiles(tiles_m < 4 ? tiles_m : 4, 256)) : 0;
+            gemm_s8_sp256<OUT, 0, TM, TN, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, nullptr, 1);
             return;
         }
     }
@@ -1060,7 +1090,7 @@ constexpr int R_TILE = 128, R_NBUF = 4, R_OPER = 128 * FBK /* 16 KiB */, R_BUF =
 // exactly where the 4-wave form has its barrier, so the ring protocol (and every result bit) is unchanged.
 template <int OUT, bool LC = false>
 __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
-                                                       int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n) {
+                                                       int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[R_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1088,15 +1118,39 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
         offP[jj] = (uint32_t)nl * (uint32_t)ldw + src_chunk * 16;
         offQ[jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
     }
-    const int8_t* gP = W + (int64_t)n0 * ldw;
-    const int8_t* gQ = X + (int64_t)m0 * ldx;
+    // K walk (round 4, LC form): the up-to-8 workgroups of a band that stream one weight panel (neighbours on one XCD, started together) walk each chunk of
+    // `ct` K-tiles from different starting points and wrap inside the chunk (gemm_s8_ring.hip: "K ROTATION in chunks") — in lockstep the panel's unique bytes in
+    // flight are one workgroup's ring, which is what an HBM-fed launch of these tiles lacks.  rot_div = 0 (and the 4-wave form): the plain walk.  Same bits.
+    const int NTw = K / FBK;
+    auto rot_of = [&](int len) { return rot_div > 0 ? (int)(((int64_t)((tin % gm) % rot_div) * len) / rot_div) : 0; };
+    int cbase = 0, clen = (LC && ct < NTw) ? ct : NTw;
+    int cpos = LC ? rot_of(clen) : 0, cleft = clen;
+    const int8_t* const gP0 = W + (int64_t)n0 * ldw;
+    const int8_t* const gQ0 = X + (int64_t)m0 * ldx;
+    // (the walk's offset goes through readfirstlane: the rotation's division is vector code, and the DMA's base operand must be provably wave-uniform)
+    const int8_t* gP = gP0 + __builtin_amdgcn_readfirstlane(cpos * FBK);
+    const int8_t* gQ = gQ0 + __builtin_amdgcn_readfirstlane(cpos * FBK);
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
-    auto dma_item = [&](int buf, auto gc) {      // piece g of the next K-tile: 0..3 P, 4..7 Q; the 8th advances the K cursor
+    auto dma_item = [&](int buf, auto gc) {      // piece g of the next K-tile: 0..3 P, 4..7 Q; the 8th moves the K walk on
         constexpr int g = decltype(gc)::value;
         const uint32_t la = smem_base + buf * R_BUF + (g >= 4 ? R_OPER : 0) + (w * 4 + (g & 3)) * 1024;
         if constexpr (g < 4) glds16_sbase(gP, offP[g], la);
         else glds16_sbase(gQ, offQ[g - 4], la);
-        if constexpr (g == 7) { gP += FBK; gQ += FBK; }
+        if constexpr (g == 7) {
+            if constexpr (!LC) { gP += FBK; gQ += FBK; }
+            else {
+                if (++cpos == clen) cpos = 0;
+                if (--cleft == 0) {
+                    cbase += clen;
+                    clen = NTw - cbase < ct ? NTw - cbase : ct;
+                    cleft = clen;
+                    cpos = clen > 0 ? rot_of(clen) : 0;
+                }
+                const int koff = __builtin_amdgcn_readfirstlane((cbase + cpos) * FBK);
+                gP = gP0 + koff;
+                gQ = gQ0 + koff;
+            }
+        }
     };
 
     // ---- fragments: P tile i = rows wp*64 + i*16 .. +15, Q tile j = rows wq*64 + j*16 .. +15; k-step ks = 64 bytes
@@ -1261,8 +1315,13 @@ template <int OUT>
 void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
                          int64_t K, hipStream_t st) {
     const int tiles_m = (int)((M + R_TILE - 1) / R_TILE), tiles_n = (int)((N + R_TILE - 1) / R_TILE);
-    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
-    else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+    // K rotation (LC form), chunks of rot_chunk_ktiles() K-tiles: HBM-fed launches lose their lockstep penalty — 4096 x 1024 x 8192 37.5 -> 33.9 us, 2048 x 1024 x 8192
+    // 34.4 -> 26.8, 4096 x 1024 x 28672 127.6 -> 102.4 — for 4 - 5 % on cache-warm replays; PQ_RING_ROT=0 switches it off (A/B: profiles/r04_rotation.txt)
+    const int gmx = tiles_m < 8 ? tiles_m : 8;
+    const int rot_div = (opt().ring_rot && N * K >= (6 << 20)) ? gmx : 0;      // weight streams that matter: below ~6 MiB the rotation only costs (4096 x 512 x 8192: -5 %)
+    const int ct = opt().ring_rot > 1 ? opt().ring_rot : rot_chunk_ktiles(gmx, 128);
+    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div);
+    else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1 << 30, 0);
 }
 template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     const int8_t* const gQ0 = X + (int64_t)m0 * ldx;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto stage1 = [&](uint32_t la) {                           // this loader wave's pieces of its next K-tile, then the K walk moves on
-        const int64_t koff = (int64_t)(cbase + cpos) * FBK;
+        const int koff = __builtin_amdgcn_readfirstlane((cbase + cpos) * FBK);      // (the rotation's division is vector code; the DMA's base operand must be provably wave-uniform)
         const int8_t* gP = gP0 + koff;
         const int8_t* gQ = gQ0 + koff;
 #pragma unroll
@@ -228,13 +228,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     }
 }
 
-// K-tiles per rotation chunk: the chunk of every weight panel an XCD streams at one time (32 CUs -> 32 / tiles_m panels of tn rows) within ~2 MiB of its 4-MiB L2 (measured: profiles/r04_midm.txt — 8 .. 32 K-tiles per chunk within 3 %, 64 and whole-K rotation up to 2x slower).
-// PQ_MIDM_CT (experiments): 0 = by this rule, 1 = no rotation, n > 1 = n K-tiles per chunk.
+// PQ_MIDM_CT (experiments): 0 = rot_chunk_ktiles(), 1 = no rotation, n > 1 = n K-tiles per chunk.
 static void rot_plan(int tiles_m, int tn, int* ct, int* rot_div) {
     const int force = opt().midm_ct;
-    const int panels = (32 + tiles_m - 1) / tiles_m;
-    int c = force > 1 ? force : (int)((2 << 20) / ((int64_t)panels * tn * FBK));
-    *ct = c < 4 ? 4 : c;
+    *ct = force > 1 ? force : rot_chunk_ktiles(tiles_m, tn);
     *rot_div = force == 1 ? 0 : tiles_m;
 }
 

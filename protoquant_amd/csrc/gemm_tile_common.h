@@ -49,6 +49,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// K-tiles per rotation chunk of the loader / consumer tiles ("K ROTATION in chunks", gemm_s8_ring.hip): the chunk of every weight panel an XCD streams at one time
+// (32 CUs -> 32 / sharers panels of tn rows each) within ~2 MiB of its 4-MiB L2, at most 16.  Measured (profiles/r04_rotation.txt, r04_midm_ab_raw.txt): 8 .. 32 K-tiles
+// within 3 % where they fit; a chunk that does not fit (128 x 256 tiles at 16 K-tiles: 4 MiB) is 25 % SLOWER than no rotation at all.
+inline int rot_chunk_ktiles(int sharers, int tn) {
+    const int panels = (32 + sharers - 1) / sharers;
+    int ct = (int)((2 << 20) / ((int64_t)panels * tn * FBK));
+    return ct < 4 ? 4 : (ct > 16 ? 16 : ct);
+}
+
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {

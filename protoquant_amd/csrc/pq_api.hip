@@ -77,7 +77,7 @@ thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
     const int iv = set ? atoi(value) : 0;
@@ -97,6 +97,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_SP256_ASM")) o.sp256_asm = !set || iv < 0 ? 1 : iv;     // "" = default (1)
     else if (!strcmp(name, "PQ_SP256_PERSIST")) o.sp256_persist = set && *value == '1';
     else if (!strcmp(name, "PQ_RING_LC")) o.ring_lc = !(set && *value == '0');
+    else if (!strcmp(name, "PQ_RING_ROT")) o.ring_rot = !set ? 1 : (iv < 0 ? 0 : iv);
     else if (!strcmp(name, "PQ_K1_LDS")) o.k1_lds = iv < 0 ? 0 : (iv > 65536 ? 65536 : iv);
     else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
     else if (!strcmp(name, "PQ_K1_RPW")) o.k1_rpw = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
@@ -393,10 +394,8 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     if (options().force_splitk > 1 && M > 64 && K % (128 * options().force_splitk) == 0) { *tm_out = 256; return options().force_splitk; }   // (experiments)
     if (M <= 64 || N < 1 || K < 2048) return 1;    // (M <= 64: the skinny kernel splits K inside the workgroup)
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
-    // a quarter-filled 256 x 256 grid with a very long K (the Llama-70B `down` shard, 4096 x 1024 x 28672): four slices of the split-ring tile
-    // with the asm K-loop + the reduction pass tie with the ring tile when the weights are warm (100 us) and are immune to the feed (HBM-fed:
-    // 101 against 128 us, profiles/r03_ab_splitk_asm.txt); at K = 8192 the reduction pass costs more than the better loop returns (48 against 31 us)
-    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) { *tm_out = 256; return 4; }
+    // (round 3 split the quarter-filled 256 x 256 grid with a very long K — the Llama-70B `down` shard, 4096 x 1024 x 28672 — four ways here, 99 us against 128 for the
+    // ring tile fed from HBM; since round 4 the ring tile's loaders rotate their K walk and it runs 102 us from HBM in ONE launch without a workspace: profiles/r04_rotation.txt)
     const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
     const int64_t tiles = tm == 128 ? t128 : t256;
     if (tiles > 128) return 1;
@@ -425,9 +424,9 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     // this device reports (a CU-masked or partitioned device reports fewer) — otherwise the two-pass split-K or the single-pass tile runs
     const int cus = device_cus();
     if (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) return 2 * t256 <= cus ? 2 : 0;
-    // the quarter-filled grid with a very long K (the Llama-70B `down` shard, 4096 x 1024 x 28672): four slices, four-way symmetric exchange — 91.3 / 92.1 us
-    // (warm / HBM-fed) against 98.9 / 99.3 for the two-pass split-K and 99 / 128 for the ring tile; at K = 16384 the ring tile still wins (r03_ab_fsk.txt, run 6)
-    if (t256 > 32 && t256 <= 64 && K >= 24576 && K % 512 == 0) return 4 * t256 <= cus ? 4 : 0;
+    // (the quarter-filled grid with a very long K — the Llama-70B `down` shard — ran four slices here in round 3: 91 us with the symmetric exchange, 104 in the
+    // placement-independent ticket form; the 128 x 128 ring tile with the rotated K walk does 102 us in one pass with no workspace, so it is no longer planned.
+    // PQ_FSK=4 still forces it.)
     return 0;
 }
 

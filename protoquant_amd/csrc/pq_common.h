@@ -35,6 +35,7 @@ struct Options {
     int k1_rpw = 0;                  // 0 auto, 1 / 2 forced
     bool k1_st16 = false;            // 16-byte code stores in K1: A/B in profiles/r03_k1_st16.txt
     int k1_lds = 0;                  // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU
+    int ring_rot = 1;                // PQ_RING_ROT: K rotation of the 128 x 128 ring tile's loaders (0 = off, 1 = on with the rule's chunk, n > 1 = n K-tiles per chunk)
     bool ring_lc = true;             // loader / consumer split of the 128 x 128 ring tile
     int sp128_lc = 1;                // loader / consumer split of the 128 x 256 tile: 1 = 4 consumers + 4 loaders, 0 = 8 symmetric waves, 2 = 12 waves (dev builds)
     bool sp256_p3 = true;            // split rings of the 256 x 256 tile (weights 3 slots deep)

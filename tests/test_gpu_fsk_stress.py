@@ -30,8 +30,8 @@ def _pool(pq, _lib, M, N, K, seed):
     return pool
 
 
-@pytest.mark.parametrize("M,N,K,fsk,sym", [(2048, 4096, 11008, "", False), (2048, 4096, 11008, "", True), (4096, 1024, 28672, "", False),
-                                           (4096, 1024, 28672, "", True), (4096, 4096, 4096, "2", False), (1000, 3000, 2560, "2", True),
+@pytest.mark.parametrize("M,N,K,fsk,sym", [(2048, 4096, 11008, "", False), (2048, 4096, 11008, "", True), (4096, 1024, 28672, "4", False),
+                                           (4096, 1024, 28672, "4", True), (4096, 4096, 4096, "2", False), (1000, 3000, 2560, "2", True),
                                            (4096, 1024, 8192, "4", True), (300, 520, 1920, "3", False)])
 def test_alternating_operands_on_one_workspace(M, N, K, fsk, sym, pq_opt):
     import protoquant_amd as pq
@@ -71,7 +71,7 @@ import sys, torch
 sys.path.insert(0, %r)
 import protoquant_amd as pq
 from protoquant_amd import _lib
-shapes = [(2048, 4096, 11008), (4096, 1024, 28672)]
+shapes = [(2048, 4096, 11008), (2048, 4096, 14336)]
 g = torch.Generator(device="cuda").manual_seed(7)
 jobs = []
 _lib.set_option("PQ_FSK", "0")

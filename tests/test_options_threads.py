@@ -52,7 +52,7 @@ def test_concurrent_setters_do_not_lose_each_others_switches(L):
     b = threading.Thread(target=setter, args=(b"PQ_NO_SPLITK", b"1", 3000))
     a.start(); b.start(); a.join(); b.join()
     assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) == b"ring128_16x16x64"
-    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0          # PQ_NO_SPLITK survived the other thread's writes
+    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 0           # PQ_NO_SPLITK survived the other thread's writes (planned as split-K otherwise)
     assert L.pq_set_option(b"PQ_NOT_A_SWITCH", b"1") != 0 and b"unknown option" in L.pq_last_error()
 
 
@@ -61,14 +61,14 @@ def _fsk_bytes(tiles, S):
 
 
 def test_planner_refuses_fused_splitk_beyond_the_devices_cus(L):
-    """cfg-3 `down` (128 tiles x 2 slices = 256 workgroups) and the 70B `down` shard (64 x 4 = 256): planned on a 256-CU device; on a device that
-    reports fewer CUs (CU-masked / partitioned: PQ_FAKE_CUS) the in-kernel hand-over is refused — the single-pass tile resp. the two-pass split-K runs."""
+    """cfg-3 `down` (128 tiles x 2 slices = 256 workgroups): planned on a 256-CU device; on a device that reports fewer CUs (CU-masked / partitioned:
+    PQ_FAKE_CUS) the in-kernel hand-over is refused and the single-pass 128 x 256 tile runs.  (The 70B `down` shard, planned with four slices in round 3,
+    runs the 128 x 128 ring tile with the rotated K walk since round 4: one pass, no workspace.)"""
     L.pq_set_option(b"PQ_FAKE_CUS", b"256")
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == _fsk_bytes(128, 2)
-    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == _fsk_bytes(64, 4)
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0 and L.pq_gemm_variant_name(4096, 1024, 28672, 28672, 28672) == b"ring128_16x16x64"
     L.pq_set_option(b"PQ_FAKE_CUS", b"255")
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == 0                              # -> 128 x 256 tiles, one pass
-    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 4 * 4096 * 1024 * 4           # -> two-pass split-K, 4 slabs of the whole output
     L.pq_set_option(b"PQ_FAKE_CUS", b"304")
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == _fsk_bytes(128, 2)
     # forced slice counts (experiments): the ticket form runs on any grid, the symmetric forms only when every workgroup can be resident
@@ -78,3 +78,7 @@ def test_planner_refuses_fused_splitk_beyond_the_devices_cus(L):
     L.pq_set_option(b"PQ_FSK_SYMMETRIC", b"1")
     assert L.pq_qlinear_workspace_bytes(4096, 4096, 4096) == 0
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 4096) == _fsk_bytes(128, 2)
+    L.pq_set_option(b"PQ_FSK", b"4")
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == _fsk_bytes(64, 4)              # forced: 64 tiles x 4 slices = 256 workgroups fit
+    L.pq_set_option(b"PQ_FAKE_CUS", b"255")
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0                              # ... and do not on a 255-CU device (symmetric form)
