@@ -184,7 +184,7 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
         // the LDS (a small tile moves 3 bytes through the LDS per byte it ingests), and a K split over workgroups costs as much hand-over latency as it saves on launches
         // this short.  Rounds of the 256 CUs x the measured time of one tile relative to the 128 x 128 ring tile (K = 4096: 14.0 / 13.4 / 9.2 us; profiles/r04_midm.txt);
         // PQ_NO_MIDM=1 restores the round-3 dispatch.
-        if (M <= 512 && !options().no_midm && options().force_splitk <= 1 && options().fsk <= 1) {      // (a forced slice count — experiments, tests — means the split-K forms)
+        if (!options().no_midm && options().force_splitk <= 1 && options().fsk <= 1) {      // (a forced slice count — experiments, tests — means the split-K forms)
             auto rounds = [](int64_t tiles) { return (double)((tiles + 255) / 256); };
             const double c128 = rounds(t128sq) * 1.00, c64x128 = rounds(((M + 63) / 64) * ((N + 127) / 128)) * 0.95, c64x64 = rounds(((M + 63) / 64) * ((N + 63) / 64)) * 0.66;
             if (c64x64 < c128 && c64x64 <= c64x128) return V_RING64X64;

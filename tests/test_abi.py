@@ -30,7 +30,11 @@ def test_library_exports_every_declared_symbol():
     assert L.pq_version() == _lib.ABI_VERSION
     assert L.pq_qlinear_workspace_bytes(4096, 4096, 4096) == 0                       # headline shape: single pass
     assert L.pq_qlinear_workspace_bytes(4096, 1024, 8192) == 0                        # 70B q/o shard: 128 x 128 ring tiles, no workspace
-    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 4 * 1024 * 1024 * 4      # quarter-filled grid, long K: split-K x4
+    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 0                         # small grid: 64 x 64 ring tiles on every CU, single pass (round 4)
+    assert L.pq_gemm_variant_name(1024, 1024, 8192, 8192, 8192) == b"ring64x64_16x16x64"
+    assert L.pq_set_option(b"PQ_NO_MIDM", b"1") == 0
+    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 4 * 1024 * 1024 * 4      # ... the round-3 plan for it: quarter-filled grid, long K: split-K x4
+    assert L.pq_set_option(b"PQ_NO_MIDM", b"") == 0
     assert L.pq_gemm_variant_name(4096, 1024, 8192, 8192, 8192) == b"ring128_16x16x64"
     assert L.pq_gemm_variant_name(16, 4096, 4096, 4096, 4096) == b"skinny_16x16x64"               # decode-like: weight streaming
     assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) == b"sp256_16x16x64"

@@ -113,11 +113,14 @@ def test_70b_shard_splitk_forced_on_matches(pq, pq_opt):
     grid, K >= 8192 -> 4 slices) against the single-pass result, bit for bit, plus the oracle on sampled rows."""
     from protoquant_amd import _lib
     M, N, K = 4096, 512, 8192
+    assert _lib.lib().pq_gemm_variant_name(M, N, K, K, K) == b"ring64x128_16x16x64" and _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0   # the default since round 4
+    y0, _ = _check(pq, M, N, K, "ring64x128")
+    pq_opt("PQ_NO_MIDM", "1")                         # the round-3 plan: 128 x 128 ring tiles' grid is a quarter of the chip -> split-K through the workspace
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0
     y, _ = _check(pq, M, N, K, "")
     pq_opt("PQ_NO_SPLITK", "1")
     y2, _ = _check(pq, M, N, K, "")
-    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)) and torch.equal(y.view(torch.int16), y0.view(torch.int16))
 
 
 @pytest.mark.parametrize("H,Kfull,name", [(8192, 8192, "o"), (8192, 28672, "down")])

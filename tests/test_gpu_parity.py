@@ -208,11 +208,11 @@ def test_qlinear_unaligned_scales_and_output(pq):
                                               (200, 2048, 14336, 1, False)])
 def test_splitk_bit_identical(pq, M, N, K, code, bias, pq_opt):
     """Small M*N / long K: the workspace-based split-K path (exact integer slab reduction) == the oracle, and
-    == the single-pass kernel (PQ_NO_SPLITK).  (M <= 512: since round 4 the dispatcher prefers the single-pass 64-row ring tiles there; PQ_NO_MIDM=1 keeps
+    == the single-pass kernel (PQ_NO_SPLITK).  (Small grids: since round 4 the dispatcher prefers the single-pass 64-row ring tiles there; PQ_NO_MIDM=1 keeps
     the two-pass path covered at those shapes too.)"""
     from protoquant_amd import _lib
-    if M <= 512:
-        assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0 and _lib.lib().pq_gemm_variant_name(M, N, K, K, K).startswith(b"ring64")
+    if _lib.lib().pq_gemm_variant_name(M, N, K, K, K).startswith(b"ring64"):
+        assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == 0
         pq_opt("PQ_NO_MIDM", "1")
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0, "shape should be planned as split-K"
     rng = np.random.default_rng(M + N + K)
@@ -384,10 +384,11 @@ def test_split_rings_bit_identical(pq, M, N, K, code, bias, pq_opt):
     same(pq.int_mm(ta, tb), acc, "2-deep ring acc")
 
 
-def test_splitk_workspace_too_small_is_an_error(pq):
+def test_splitk_workspace_too_small_is_an_error(pq, pq_opt):
     from protoquant_amd import _lib
     L = _lib.lib()
-    M, N, K = 1024, 1024, 8192          # (a quarter-filled grid with a long K: planned as split-K; M <= 512 runs the single-pass 64-row ring tiles since round 4)
+    M, N, K = 1024, 1024, 8192          # (a quarter-filled grid with a long K: the round-3 plan is split-K; the default since round 4 is the single-pass 64 x 64 ring tile)
+    pq_opt("PQ_NO_MIDM", "1")
     need = L.pq_qlinear_workspace_bytes(M, N, K)
     assert need > 0
     a = torch.zeros((M, K), dtype=torch.int8, device="cuda"); b = torch.zeros((N, K), dtype=torch.int8, device="cuda")
@@ -1114,10 +1115,11 @@ def test_errors_are_loud(pq):
 
 @pytest.mark.parametrize("M,N,K,want", [(65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
                                         (384, 4096, 14336, "ring64x128"), (512, 4096, 4096, "ring64x128"), (512, 4096, 14336, "ring64x128"), (500, 4000, 1152, "ring64x128"),
-                                        (128, 28672, 4096, "ring128"), (512, 28672, 4096, "sp256")])
+                                        (128, 28672, 4096, "ring128"), (512, 28672, 4096, "sp256"), (1024, 1024, 8192, "ring64x64"), (2048, 1024, 8192, "ring64x128"),
+                                        (640, 2048, 4096, "ring64x128"), (4096, 1024, 8192, "ring128")])
 def test_mid_m_regime_exact(pq, M, N, K, want, pq_opt):
-    """64 < M <= 512 (round-3 verdict item 4): the 64-row ring tiles of gemm_s8_ring.hip, chosen by the dispatcher when the 128 x 128 ring tiles would fill well
-    under the chip.  Full-range int8 operands: int32 accumulator == an exact float64 matmul, y == the QSPEC epilogue (bias, every output dtype), ==
+    """64 < M <= 512 (round-3 verdict item 4) and other small grids: the 64-row ring tiles of gemm_s8_ring.hip, chosen by the dispatcher when the 128 x 128 ring tiles
+    would fill well under the chip.  Full-range int8 operands: int32 accumulator == an exact float64 matmul, y == the QSPEC epilogue (bias, every output dtype), ==
     the round-3 dispatch (PQ_NO_MIDM=1) bit for bit, ragged M / N included."""
     from protoquant_amd import _lib
     name = _lib.lib().pq_gemm_variant_name(M, N, K, K, K).decode()

@@ -11,7 +11,7 @@ from protoquant_amd import _lib
 def L():
     lib = _lib.lib()
     yield lib
-    for n in ("PQ_FORCE_VARIANT", "PQ_FAKE_CUS", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_NO_SPLITK"):
+    for n in ("PQ_FORCE_VARIANT", "PQ_FAKE_CUS", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_NO_SPLITK", "PQ_NO_MIDM", "PQ_NO_TAILSPLIT"):
         _lib.set_option(n, "")
 
 
@@ -48,11 +48,11 @@ def test_concurrent_setters_do_not_lose_each_others_switches(L):
     def setter(name, val, n):
         for _ in range(n):
             assert L.pq_set_option(name, val) == 0
-    a = threading.Thread(target=setter, args=(b"PQ_FORCE_VARIANT", b"ring128", 3000))
-    b = threading.Thread(target=setter, args=(b"PQ_NO_SPLITK", b"1", 3000))
+    a = threading.Thread(target=setter, args=(b"PQ_NO_TAILSPLIT", b"1", 3000))
+    b = threading.Thread(target=setter, args=(b"PQ_NO_MIDM", b"1", 3000))
     a.start(); b.start(); a.join(); b.join()
-    assert L.pq_gemm_variant_name(4096, 4096, 4096, 4096, 4096) == b"ring128_16x16x64"
-    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) == 0           # PQ_NO_SPLITK survived the other thread's writes (planned as split-K otherwise)
+    assert L.pq_gemm_variant_name(4096, 6144, 4096, 4096, 4096) == b"sp256_16x16x64"          # PQ_NO_TAILSPLIT survived (a tail split otherwise)
+    assert L.pq_qlinear_workspace_bytes(1024, 1024, 8192) > 0            # PQ_NO_MIDM survived the other thread's writes (0 = the 64 x 64 ring tiles otherwise)
     assert L.pq_set_option(b"PQ_NOT_A_SWITCH", b"1") != 0 and b"unknown option" in L.pq_last_error()
 
 
