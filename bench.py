@@ -479,8 +479,10 @@ def run_llama70b_shard(args):
         wq = (torch.randn(n, k, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
         return pq.qlinear.from_qtensor(QTensor(wq, torch.rand(n, device=dev) * 1e-3 + 1e-4, 1, torch.bfloat16, wq.shape))
     n_qkv, n_o, n_gu, n_down, n_head = (H + 2 * KVD) // G, H // G, 2 * I // G, H // G, V // G
-    # two distinct layers' weights alternate (80 x 1.1 GB of shards would fit, but two already defeat any cache reuse between layers)
-    layers = [(mkq(n_qkv, H), mkq(n_o, H), mkq(n_gu, H), mkq(n_down, I)) for _ in range(2)]
+    # NL distinct layers' weights take turns (105 MB of shards per layer: two sets would sit in the 256-MB Infinity Cache; eight — 840 MB — make every layer stream its
+    # weights from HBM, as the 80 distinct layers of the model do)
+    NL = 8
+    layers = [(mkq(n_qkv, H), mkq(n_o, H), mkq(n_gu, H), mkq(n_down, I)) for _ in range(NL)]
     head = mkq(n_head, H)
     x_h = torch.randn(M, H, device=dev).to(torch.bfloat16)          # stands for a gathered hidden state
     x_i = torch.randn(M, I, device=dev).to(torch.bfloat16)          # stands for the gathered silu(g) * u
@@ -488,7 +490,7 @@ def run_llama70b_shard(args):
 
     def fwd():
         for l in range(L):
-            qkv, o, gu, down = layers[l & 1]
+            qkv, o, gu, down = layers[l % NL]
             qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
             o(x_h)
             gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
@@ -510,13 +512,13 @@ def run_llama70b_shard(args):
     # per rank, GEMM shapes 4096 x 8192 x 1024 and 4096 x 8192 x 3584 instead of the 1024-wide column shards.
     pairing = None
     try:
-        rl = [(mkq(H, H // G), mkq(H, I // G)) for _ in range(2)]
+        rl = [(mkq(H, H // G), mkq(H, I // G)) for _ in range(NL)]
         x_a = torch.randn(M, H // G, device=dev).to(torch.bfloat16)          # stands for this rank's heads of the attention output
 
         def fwd_row():
             for l in range(L):
-                qkv, _o, gu, _d = layers[l & 1]
-                o_r, d_r = rl[l & 1]
+                qkv, _o, gu, _d = layers[l % NL]
+                o_r, d_r = rl[l % NL]
                 qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
                 xa = pq.quantize(x_a)
                 pq.qlinear_s8(xa.int_data, xa.scale, o_r.wq, o_r.ws, None, torch.float32)
@@ -540,8 +542,8 @@ def run_llama70b_shard(args):
         del rl
     except Exception as e:      # an extra figure must never lose the main line
         print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
-    # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (two alternating weight sets; shards of 8 - 60 MB:
-    # Infinity-Cache-warm, so the sum is a little below the step, whose weights cycle through ~210 MB), with its share of the layer and — for the GEMMs —
+    # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (all NL weight sets in turn: HBM-fed like the step),
+    # with its share of the layer and — for the GEMMs —
     # its fraction of the int8 peak: the per-shape account of the distance to 0.50
     per_shape = None
     try:
@@ -566,7 +568,7 @@ def run_llama70b_shard(args):
                  ("down shard", (M, n_down, I), lambda l: layers[l][3](qi), 1)]
         per_shape, tot = [], 0.0
         for name, shp, fn, mult in items:
-            us = ev_graph(lambda: (fn(0), fn(1)), 4) / 2
+            us = ev_graph(lambda: [fn(l) for l in range(NL)], 2) / NL
             tot += us * mult
             d = {"kernel": name, "us": round(us, 1), "per_layer": mult}
             if shp is not None:
