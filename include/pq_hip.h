@@ -49,7 +49,7 @@ int32_t pq_version(void);
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
  * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
- * split-K, S = S slices), PQ_FSK_SYMMETRIC (see pq_qlinear_s8), PQ_FAKE_CUS (plan as if the device had n CUs),
+ * split-K, S = S slices), PQ_FSK_SYMMETRIC and PQ_FSK_FENCED (see pq_qlinear_s8), PQ_NO_MIDM (no 64-row ring tiles), PQ_RING_ROT (0 = no K rotation), PQ_FAKE_CUS (plan as if the device had n CUs),
  * PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the first call into the
  * library; this call changes a switch afterwards.
  * Threading: the switches live in an immutable snapshot; pq_set_option publishes a modified copy with one atomic pointer
@@ -111,6 +111,10 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
  * the workgroups of a tile that finish first store their partial sums and leave, the last one adds them — so it is safe
  * under any placement: several such GEMMs on concurrent streams, CU-masked queues, partitioned devices, a co-running
  * persistent kernel.  It is planned only when tiles x slices <= the CUs the current device reports (a performance rule).
+ * Visibility of the handed-over sums rests on write-through (sc1) stores whose acknowledgement (vmcnt) precedes the ticket,
+ * and agent-scope (sc1) loads behind a poll + barrier: a sequence measured valid on gfx950 / ROCm 7.2, not
+ * an architectural guarantee; PQ_FSK_FENCED=1 adds the documented release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) as
+ * a fallback, at ~35 us per launch.
  * PQ_FSK_SYMMETRIC=1 opts into the symmetric exchange for 2 / 4 slices (each workgroup keeps a part of the tile and
  * WAITS for its partners' contributions: 2-5 % faster): the caller then guarantees that every workgroup of the launch
  * can be resident at once — no second fused split-K GEMM in flight on another stream, no CU mask — and the planner

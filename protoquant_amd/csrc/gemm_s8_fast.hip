@@ -509,7 +509,8 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
                 // the hand-over: the first kslices - 1 workgroups of a tile to arrive END inside this statement, the last leaves it with the tile's sums
                 unsigned* const ctr = reinterpret_cast<unsigned*>(stamps);
                 const uint8_t* const slab0 = reinterpret_cast<const uint8_t*>(stamps) + fsk_counter_bytes(ntiles_all, kslices) + (size_t)t * (size_t)(kslices - 1) * (256 * 256 * 4);
-                fsk_tail_asm(acc, ctr + t, ctr + ntiles_all + t, slab0, (uint32_t)(kslices - 1), smem_base + (uint32_t)scale_off + 2048u, (uint32_t)wave);
+                fsk_tail_asm(acc, ctr + t, ctr + ntiles_all + t, slab0, (uint32_t)(kslices - 1), smem_base + (uint32_t)scale_off + 2048u, (uint32_t)wave,
+                             (uint32_t)__builtin_amdgcn_readfirstlane(dbg));          // (`dbg` of this kernel form: PQ_FSK_FENCED)
             } else if constexpr (FSK >= 2) {
                 // the exchange: this workgroup leaves the statement with the tile's sums in accumulator part `kslice`
                 const unsigned* const flags = reinterpret_cast<const unsigned*>(stamps) + FSK * t;
@@ -1003,7 +1004,7 @@ bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
     else if (kslices == 4 && sym)
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 4);
     else
-        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, kslices);
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, opt().fsk_fenced ? 1 : 0, ws, kslices);
     return true;
 }
 template bool launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);

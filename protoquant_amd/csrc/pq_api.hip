@@ -76,7 +76,7 @@ thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by
 thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
@@ -87,6 +87,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_FORCE_SPLITK")) o.force_splitk = iv;
     else if (!strcmp(name, "PQ_FSK")) o.fsk = set ? iv : -1;
     else if (!strcmp(name, "PQ_FSK_SYMMETRIC")) o.fsk_symmetric = set && *value == '1';
+    else if (!strcmp(name, "PQ_FSK_FENCED")) o.fsk_fenced = set && *value == '1';
     else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_NO_MIDM")) o.no_midm = set;
     else if (!strcmp(name, "PQ_MIDM_CT")) o.midm_ct = iv > 0 ? iv : 0;

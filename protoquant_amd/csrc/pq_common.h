@@ -30,6 +30,7 @@ struct Options {
     bool fsk_symmetric = false;      // PQ_FSK_SYMMETRIC=1: the symmetric exchange for 2 / 4 slices (waits for partner workgroups: see pq_hip.h); default: the ticket form
     int midm_ct = 0;                 // PQ_MIDM_CT: K-tiles per rotation chunk of the mid-M ring tiles (0 = by rule, 1 = no rotation)
     bool no_midm = false;            // PQ_NO_MIDM=1: no 64-row ring tiles for 64 < M <= 512 (the round-3 dispatch)
+    bool fsk_fenced = false;         // PQ_FSK_FENCED=1: the ticket hand-over with the documented agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) as well
     int fake_cus = 0;                // PQ_FAKE_CUS=n: plan as if the device had n CUs (tests of the residency guard)
     int skinny_rb = 0;               // 0 auto, 1 / 2 forced
     int k1_rpw = 0;                  // 0 auto, 1 / 2 forced

@@ -32,13 +32,14 @@ def _pool(pq, _lib, M, N, K, seed):
 
 @pytest.mark.parametrize("M,N,K,fsk,sym", [(2048, 4096, 11008, "", False), (2048, 4096, 11008, "", True), (4096, 1024, 28672, "4", False),
                                            (4096, 1024, 28672, "4", True), (4096, 4096, 4096, "2", False), (1000, 3000, 2560, "2", True),
-                                           (4096, 1024, 8192, "4", True), (300, 520, 1920, "3", False)])
+                                           (4096, 1024, 8192, "4", True), (300, 520, 1920, "3", False), (2048, 4096, 11520, "3", False)])
 def test_alternating_operands_on_one_workspace(M, N, K, fsk, sym, pq_opt):
     import protoquant_amd as pq
     from protoquant_amd import _lib
     pool = _pool(pq, _lib, M, N, K, M + N + K)
     pq_opt("PQ_FSK", fsk)
     pq_opt("PQ_FSK_SYMMETRIC", "1" if sym else "")
+    pq_opt("PQ_FSK_FENCED", "1" if (not sym and fsk == "3") else "")       # one case through the fenced fallback (buffer_wbl2 / buffer_inv as well): same bits
     assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0
     nbad = 0
     for i in range(60):

@@ -434,6 +434,14 @@ def gen_fsk_tail(E):
         R(f"global_store_dwordx4 {t0}, {accq(g)}, %[slab]" + off(g) + " sc1", 8)
         if g % 4 == 3 and g < 31:
             R(f"v_add_u32 {t0}, 0x1000, {t0}", 8)
+    # PQ_FSK_FENCED=1 (fallback; `fen` != 0): the documented agent-scope release — write back this XCD's L2 — in front of the drain, instead of relying on the
+    # acknowledgement of a write-through store meaning device-wide visibility (measured valid on gfx950 / ROCm 7.2: MI355X_MICROARCH.md, "Hand-offs measured with sc1
+    # loads in place of the acquire", third row — a counter of agent-scope atomic adds by one lane of each storing workgroup, an sc1 poll, a barrier between the poll and
+    # every load, dwordx4 sc1 stores that write whole lines, dwordx4 sc1 loads — not an architectural guarantee; tests/test_gpu_fsk_stress.py re-checks it on every GPU run)
+    R("s_cmp_eq_u32 %[fen], 0")
+    R("s_cbranch_scc1 L_fsk_nf1_%=")
+    R("buffer_wbl2 sc1", 8)
+    E.label("L_fsk_nf1_%=")
     R("s_waitcnt vmcnt(0)")                                  # (write-through stores: acknowledged = visible to the agent; no L2 write-back needed)
     R("s_barrier")
     R("s_cmp_lg_u32 %[wv], 0")
@@ -464,6 +472,11 @@ def gen_fsk_tail(E):
     R("s_mov_b64 exec, %[sx]")
     E.label("L_fsk_polled_%=")
     R("s_barrier")
+    R("s_cmp_eq_u32 %[fen], 0")                              # PQ_FSK_FENCED=1: the documented agent-scope acquire (invalidate this CU's L1) behind the poll
+    R("s_cbranch_scc1 L_fsk_nf2_%=")
+    R("buffer_inv sc1", 8)
+    R("s_waitcnt vmcnt(0)")
+    E.label("L_fsk_nf2_%=")
     R("s_mov_b32 %[st1], 0")                                 # (the slab loads are agent-scope loads themselves: no cache invalidate)
     E.label("L_fsk_slab_%=")
     R("s_lshl_b32 %[st0], %[st1], 18")
@@ -643,8 +656,8 @@ def render_fsk_tail():
            f"// pinned (FSK_ACC_REG in the generator), the {FSK_NTMP + 1} fragment quads (FSK_TMP_REG) are the statement's temporaries.  A workgroup that is not the last of",
            "// its tile to arrive ENDS inside the statement."]
     a = _render_tail("fsk_tail_asm", doc, gen_fsk_tail,
-                     "const void* fsk_tick, const void* fsk_ready, const void* fsk_slab,\n        uint32_t fsk_nsl, uint32_t fsk_lds, uint32_t fsk_wave",
-                     ['[tick] "s"(fsk_tick)', '[rdy] "s"(fsk_ready)', '[slab] "s"(fsk_slab)', '[nsl] "s"(fsk_nsl)', '[tkl] "s"(fsk_lds)', '[wv] "s"(fsk_wave)'])
+                     "const void* fsk_tick, const void* fsk_ready, const void* fsk_slab,\n        uint32_t fsk_nsl, uint32_t fsk_lds, uint32_t fsk_wave, uint32_t fsk_fenced",
+                     ['[tick] "s"(fsk_tick)', '[rdy] "s"(fsk_ready)', '[slab] "s"(fsk_slab)', '[nsl] "s"(fsk_nsl)', '[tkl] "s"(fsk_lds)', '[wv] "s"(fsk_wave)', '[fen] "s"(fsk_fenced)'])
     out = a
     for S in (2, 4):
         doc = [f"// fsk_sym{S}_asm: the symmetric exchange of the {S}-slice form (gen_fsk_sym_tail): slice s leaves the statement with the tile's sums in",
