@@ -31,7 +31,7 @@ def test_headline_json_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TOP/s" and r["peak"] == 5033.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.2 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 6e7)
     # the same kernel with its weights streamed from HBM (as inside a model): never faster than the cache-resident replay by more than noise
-    assert r["avg_kernel_us_weights_from_hbm"] and r["avg_kernel_us_weights_from_hbm"] > 0.97 * r["avg_kernel_us"]
+    assert r["avg_kernel_us_weights_from_hbm"] and r["avg_kernel_us_weights_from_hbm"] > 0.95 * r["avg_kernel_us_same_rounds_as_hbm_leg"] > 0.9 * r["avg_kernel_us"]
     # the line is reproducible from itself: GEMM + K1 (gap-free replays) fit the step, the timed region is repeated blocks
     assert d["timings_consistent"] is True and d["config"]["repeats"] >= 20
     qp = d["quant_pass"]
