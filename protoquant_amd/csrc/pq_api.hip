@@ -168,10 +168,11 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     if (f == V_GENERIC || !ok) return V_GENERIC;
     if (f == V_SKINNY) return M <= 64 ? V_SKINNY : V_RING128;      // the skinny kernel holds at most 4 token tiles
     if (f != V_AUTO) return f;
-    // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us
-    // vs 18 us tiled); 2-4 token tiles re-read the activations 2-4x from L2, which only pays while the tiled grid
-    // (N / 128 tiles) cannot fill the chip (measured: N = 4096 12 vs 20 us at M = 64; N = 14336 39 vs 20 us)
-    if (M <= 16 || (M <= 64 && N <= 8192)) return V_SKINNY;
+    // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us vs 18 us tiled); two token tiles re-read the
+    // activations from L2, which pays while the tiled grid cannot fill the chip (N <= 8192).  Three and four token tiles (33 .. 64 tokens) went to this kernel until round 3;
+    // the 64-row ring tiles of round 4 are faster there at every width (64 x 4096 x 4096: 12.5 / 14.3 -> 9.5 / 12.6 us warm / HBM-fed, 64 x 6144 x 4096: 21.4 / 24.7 -> 9.7 / 13.3:
+    // profiles/r04_midm_decode.txt); PQ_NO_MIDM=1 restores the old split.
+    if (M <= 16 || (M <= (options().no_midm ? 64 : 32) && N <= 8192)) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
