@@ -48,7 +48,7 @@ int32_t pq_version(void);
 /* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
- * skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
+ * ring64x128 | ring64x64 | skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
  * split-K, S = S slices), PQ_FSK_SYMMETRIC and PQ_FSK_FENCED (see pq_qlinear_s8), PQ_NO_MIDM (no 64-row ring tiles), PQ_RING_ROT (0 = no K rotation), PQ_FAKE_CUS (plan as if the device had n CUs),
  * PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the first call into the
  * library; this call changes a switch afterwards.

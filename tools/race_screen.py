@@ -6,7 +6,10 @@ import protoquant_amd as pq
 SHAPES = [(4096, 4096, 4096, 300), (4096, 1024, 8192, 300), (2048, 4096, 11008, 200), (1000, 3000, 1024, 400), (257, 511, 256, 800),
           (512, 4096, 4096, 400), (8192, 8192, 1024, 100), (4096, 4096, 128, 500), (4096, 4096, 256, 500), (4096, 4096, 384, 500), (4096, 4096, 512, 400), (4096, 8192, 640, 300),
           (4096, 1024, 4096, 300), (4096, 1024, 28672, 60), (300, 1000, 384, 500), (16, 4096, 4096, 800), (64, 4096, 14336, 400),
-          (1, 128256, 4096, 100), (33, 777, 512, 800), (2048, 11008, 4096, 200), (1024, 1024, 8192, 300)]
+          (1, 128256, 4096, 100), (33, 777, 512, 800), (2048, 11008, 4096, 200), (1024, 1024, 8192, 300),
+          # round 4: the 64-row ring tiles (rotated K walk, one barrier per two K-tiles) and the rotated ring128 / 128 x 256 loaders
+          (128, 4096, 4096, 600), (256, 4096, 14336, 300), (500, 4000, 1152, 600), (64, 6144, 4096, 600), (200, 1000, 2048, 800), (1024, 1024, 4096, 500),
+          (4096, 1280, 8192, 200), (2048, 1024, 8192, 300), (384, 4096, 128, 800), (70, 130, 384, 800)]
 bad_total = 0
 for M, N, K, reps in SHAPES:
     torch.manual_seed(M + N + K)
