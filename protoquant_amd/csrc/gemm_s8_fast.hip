@@ -72,8 +72,9 @@ __host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles, int kslices) 
 // workspace: [tickets: ntiles u32][ready: ntiles u32] (zeroed by the launcher), padded to 256 B, then the slabs.
 // FSK = 2 / 4: the two- / four-slice SYMMETRIC exchange — workgroups S p .. S p + S - 1 share tile p; each keeps one part of the accumulators (S = 2: a column
 // half of every wave block; S = 4: a quarter = column half x row half), stores the other parts, waits for the partners' flags, adds their contributions to the
-// part it kept and runs the epilogue of that part (fsk_sym2_asm / fsk_sym4_asm): no idle CU, 1 / S of an epilogue each.  (The wait is for workgroups with
-// neighbouring ids, dispatched together with this one.)
+// part it kept and runs the epilogue of that part (fsk_sym2_asm / fsk_sym4_asm): no idle CU, 1 / S of an epilogue each.  The wait is for workgroups that may NOT
+// be running (another fused split-K launch on a second stream can hold the CUs their partners need): these forms are opt-in (PQ_FSK_SYMMETRIC=1, pq_hip.h); the default
+// is the ticket form above (FSK = 1), which never waits for a workgroup that has not finished its K-loop.
 template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4, int FSK = 0>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 : 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,

@@ -411,11 +411,10 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     return s;
 }
 
-// fused split-K (gemm_s8_sp256<..., FSK>: the partial sums of a tile's K-slices are handed over inside the GEMM kernel).  Chosen for the half-filled 256 x 256
-// grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008): two workgroups per tile, symmetric exchange.  Measured against the 128 x 256 tile
-// (profiles/r03_ab_fsk.txt, run 5): weights from HBM — what a layer inside a model sees — 73.5 against 84.1 us (K = 14336: 90.7 against 98.8; 16384: 101.4
-// against 105.7); weights warm 71.8 against 68.4 us (88.4 / 87.4, 99.1 / 99.4).  PQ_FSK=0 turns it off, PQ_FSK=S (experiments) forces S slices wherever the
-// shape admits them (S = 2 / 4: the symmetric exchanges; other S, or PQ_FSK_TICKET=1: the ticket form).
+// fused split-K (gemm_s8_sp256<..., FSK>: the partial sums of a tile's K-slices are handed over inside the GEMM kernel).  Planned for the half-filled 256 x 256
+// grid with a long K (cfg-3 `down`, 2048 x 4096 x 11008): two workgroups per tile, TICKET hand-over (placement-independent: pq_hip.h).  Measured, weights from HBM — what a
+// layer inside a model sees (profiles/r04_ab_fsk_forms.txt, r04_rotation.txt): 78.3 us against 86.0 for the 128 x 256 tile (79.2 with its rotated K walk); the symmetric
+// exchange of round 3, 76.8, is opt-in (PQ_FSK_SYMMETRIC=1).  PQ_FSK=0 turns the plan off, PQ_FSK=S (experiments) forces S slices wherever the shape admits them.
 static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     const int f = options().fsk;
     if (f == 0 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
