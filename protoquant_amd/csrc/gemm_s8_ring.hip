@@ -1,16 +1,17 @@
-// gemm_s8_ring.hip — K3/K4 for the 64 < M <= 512 regime (a few hundred tokens: short prefill chunks, speculative / batched decode):
-// y[M, N] = dequant(xq[M, K] . wq[N, K]^T) when the 128-row tiles of gemm_s8_fast.hip fill at most half of the 256 CUs.
+// gemm_s8_ring.hip — K3/K4 for SMALL GRIDS: 33 .. 512 tokens (short prefill chunks, speculative / batched decode) and any other problem whose 128 x 128 ring tiles
+// (gemm_s8_ring128) would fill well under the 256 CUs: y[M, N] = dequant(xq[M, K] . wq[N, K]^T) on 64(m) x 128(n) or 64 x 64 tiles, one per CU on every CU.
 //
-// What bounds this regime ("mid-M"): not the matrix pipe and not HBM but the L2 -> CU path.  A CU ingests ~50 B/clk
-// (103 - 116 GB/s per CU, 26 TB/s over the chip: profiles/r01_ubench_l2_ingest.txt) and an output tile of tm x tn pulls (tm + tn) bytes per
-// K element for 2 tm tn operations: a 128 x 128 tile wants 64 B/clk to keep its MFMAs fed, and M = 512 x N = 4096 makes only 128 of them.
-// Splitting K over workgroups (the fused hand-over of the big tile) costs ~3 - 4 us of store -> ticket -> load latency, as much as it saves
-// on a 10-us launch.  So this kernel goes the other way: SMALLER tiles, one per CU on every CU — 64(m) x 128(n) (M = 512: 256 tiles at
-// N = 4096) or 64 x 64 (M = 256) — with the loader / consumer structure of the 128 x 128 ring tile (gemm_s8_ring128) and a DEEPER ring
-// (3 slots x 2 K-tiles x 24 KiB, 4 x 2 x 16 KiB; one barrier per SLOT): the weight pieces of a model layer come from HBM, and with tiles this short nothing else hides their first touch.
+// What bounds the regime: neither the matrix pipe nor HBM but the LDS and the L2 -> CU path.  A tile of tm x tn rows moves (tm + tn) x 128 bytes into the
+// LDS per K-tile (LDS-DMA) and reads twice that back as MFMA fragments (four consumer waves, 2 x 2 over the tile: every byte is read by two of them): 3 LDS bytes per ingested
+// byte at 128 B/clk — 384 cycles per K-tile for a 64 x 64 tile against 128 of MFMA (measured ~400), 576 for 64 x 128 (~680), 768 for the 128 x 128 ring tile (~720) — and a CU
+// ingests ~50 B/clk (26 TB/s over the chip: profiles/r01_ubench_l2_ingest.txt).  M = 512 x N = 4096 makes only 128 tiles of 128 x 128: half the chip at the LDS-bound rate.
+// Splitting K over workgroups (the fused hand-over of the big tile) costs ~3 - 4 us of store -> ticket -> load latency, as much as it saves on a 10-us launch.  So this kernel
+// goes the other way: smaller tiles on EVERY CU, with the loader / consumer structure of the ring tile, rings of 3 slots x 2 K-tiles x 24 KiB / 4 x 2 x 16 KiB (one barrier per
+// slot) and a K walk rotated between the workgroups that share a weight panel (below).  The dispatcher (pq_api.hip: pick_variant) chooses between the three ring tiles by
+// rounds of 256 CUs x the measured time of one tile.
 //   * 8 waves: waves 0-3 consume (2 x 2 over the tile: wave tile (TN/2) n x (TM/2) m, fragments of the next K-tile read in the shadows of the
 //     current one's MFMAs, double-buffered in registers), waves 4-7 issue the LDS-DMA pieces (8 rows x 128 B each) of tile kt + NB and do the
-//     counted vmcnt waits; ONE s_barrier per K-tile joins the roles.
+//     counted vmcnt waits; ONE s_barrier per ring slot (two K-tiles) joins the roles.
 //   * LDS image as everywhere: [rows][128 B], 16-byte chunk c of row r at c ^ ((r >> 1) & 7) — swizzle on the DMA's per-lane SOURCE address and
 //     on the ds_read_b128 address.
 //   * epilogue: gemm_epilogue.h (QSPEC E1-E4 in registers, wave-private transpose through a free ring slot, write-through 16-byte stores);
