@@ -19,10 +19,15 @@ constexpr int sk_batch(int mt) { return mt == 1 ? 8 : (mt == 2 ? 4 : 2); }
 // RB: 16-row weight blocks per wave.  The direct-to-fragment access pattern (16 segments of 64 B per instruction) tops out
 // near 9.8 TB/s over the whole chip (tools/ubench/l2_ingest), and the activation fragments travel the same path from L2:
 // with RB = 1 and one token tile they take half of it.  RB = 2 reuses every activation fragment for two weight blocks.
-template <int OUT, int MT, int RB>       // MT: 16-row tiles of activations (M <= 16 * MT)
+// STAGE (round 4): the activation fragments no longer come straight from L2 in the MFMA operand layout (16 rows x 64 B per load instruction — the same 16-segment request the
+// weight fragments need, on the same vector-memory pipeline: with one weight block per wave HALF of that pipeline's requests were activation re-reads, and 16 tokens ran 15 - 40 %
+// slower than 1 token, whose 16 "rows" are one clamped row).  A wave now loads its K-batch of the token rows with row-contiguous requests (2 - 4 rows x 256 - 512 B per
+// instruction), parks them in a wave-private LDS region (row stride padded by 16 B: conflict-free both ways) and reads the fragments back with ds_read_b128.  Same values, same
+// MFMAs: bit-identical.
+template <int OUT, int MT, int RB, bool STAGE>       // MT: 16-row tiles of activations (M <= 16 * MT)
 __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
                                                        int64_t ldw, EpiArgs epi, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sk_smem[];     // [KS][MT][64 lanes] v4i
+    extern __shared__ __attribute__((aligned(16))) uint8_t sk_smem[];     // STAGE: [KS][MT * 16 rows][SK_U * 64 + 16 B] staging, reused as [KS][MT][64 lanes] v4i for the reduction
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), KS = blockDim.x >> 6;
     const int r = lane & 15, c = lane >> 4;
@@ -49,6 +54,19 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[b][t] = v4i{0, 0, 0, 0};
 
+    // STAGE: row-contiguous activation loads.  A batch is SK_U k-steps = UPR = 4 SK_U 16-byte units per row; a load instruction covers 64 / UPR rows.
+    constexpr int UPR = 4 * SK_U, RPI = 64 / UPR, NLD = MT * 16 / RPI;          // units per row, rows per instruction, instructions per batch
+    constexpr int RSTR = SK_U * 64 + 16;                                        // staged row stride (bytes)
+    uint8_t* const stg = sk_smem + (size_t)w * (MT * 16 * RSTR);
+    const int lrow = lane / UPR, lunit = lane % UPR;
+    const int8_t* xrow[STAGE ? NLD : 1];
+    if constexpr (STAGE) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = i * RPI + lrow < M ? i * RPI + lrow : M - 1;          // (rows past M: a valid row again; their products land in accumulator columns nobody stores)
+            xrow[i] = X + (int64_t)m * ldx + lunit * 16;
+        }
+    }
     int s = s0;
     for (; s + SK_U <= s1; s += SK_U) {
         v4i fw[SK_U][RB], fx[SK_U][MT];
@@ -56,8 +74,23 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
         for (int u = 0; u < SK_U; ++u) {
 #pragma unroll
             for (int b = 0; b < RB; ++b) fw[u][b] = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)(s + u) * 64);
+            if constexpr (!STAGE) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
+                for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
+            }
+        }
+        if constexpr (STAGE) {
+            v4i xr[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) xr[i] = *reinterpret_cast<const v4i*>(xrow[i] + (int64_t)s * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the previous batch's fragment reads have returned: its region may be overwritten
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<v4i*>(stg + (i * RPI + lrow) * RSTR + lunit * 16) = xr[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // wave-private region, LDS operations of one wave execute in order: written -> readable
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(stg + (t * 16 + r) * RSTR + (u * 4 + c) * 16);
         }
 #pragma unroll
         for (int u = 0; u < SK_U; ++u)
@@ -83,6 +116,7 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
     v4i* red = reinterpret_cast<v4i*>(sk_smem);
     constexpr int NTL = RB * MT;                          // output tiles of this workgroup: tile q = b * MT + t
     if (KS > 1) {
+        if constexpr (STAGE) __syncthreads();            // the reduction buffer overlays the staging regions of ALL waves: everybody is done with theirs
 #pragma unroll
         for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -150,8 +184,15 @@ void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t l
     const int64_t blocks = (N + 16 * rb - 1) / (16 * rb);
     const int ks = skinny_ks(blocks, K, mt * rb);
     const dim3 grid((unsigned)blocks), block((unsigned)(ks * 64));
-    const size_t lds = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;
-#define PQ_SK(MTv, RBv) gemm_s8_skinny<OUT, MTv, RBv><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K)
+    const bool stage = opt().skinny_stage && M > 1;       // (one token: its 16 "rows" are one clamped row — the direct loads are already cheap)
+    const size_t lds_red = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;
+    const size_t lds_stg = stage ? (size_t)ks * mt * 16 * (sk_batch(mt * rb) * 64 + 16) : 0;
+    const size_t lds = lds_red > lds_stg ? lds_red : lds_stg;
+    // (the staging regions of 16 waves need up to 147 KiB of dynamic LDS: above the 64-KiB default, the limit is raised once per instantiation)
+#define PQ_SK(MTv, RBv) do { if (stage) { static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s8_skinny<OUT, MTv, RBv, true>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)attr_; \
+                                  gemm_s8_skinny<OUT, MTv, RBv, true><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); } \
+                             else gemm_s8_skinny<OUT, MTv, RBv, false><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); } while (0)
     if (rb == 2) { if (mt == 1) PQ_SK(1, 2); else PQ_SK(2, 2); }
     else {
         switch (mt) {

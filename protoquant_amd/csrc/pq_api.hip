@@ -77,7 +77,7 @@ thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
     const int iv = set ? atoi(value) : 0;
@@ -102,6 +102,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_K1_LDS")) o.k1_lds = iv < 0 ? 0 : (iv > 65536 ? 65536 : iv);
     else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
     else if (!strcmp(name, "PQ_K1_RPW")) o.k1_rpw = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
+    else if (!strcmp(name, "PQ_SKINNY_STAGE")) o.skinny_stage = !(set && *value == '0');
     else if (!strcmp(name, "PQ_SKINNY_RB")) o.skinny_rb = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
     else return false;
     return true;
@@ -168,11 +169,11 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     if (f == V_GENERIC || !ok) return V_GENERIC;
     if (f == V_SKINNY) return M <= 64 ? V_SKINNY : V_RING128;      // the skinny kernel holds at most 4 token tiles
     if (f != V_AUTO) return f;
-    // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us vs 18 us tiled); two token tiles re-read the
-    // activations from L2, which pays while the tiled grid cannot fill the chip (N <= 8192).  Three and four token tiles (33 .. 64 tokens) went to this kernel until round 3;
-    // the 64-row ring tiles of round 4 are faster there at every width (64 x 4096 x 4096: 12.5 / 14.3 -> 9.5 / 12.6 us warm / HBM-fed, 64 x 6144 x 4096: 21.4 / 24.7 -> 9.7 / 13.3:
-    // profiles/r04_midm_decode.txt); PQ_NO_MIDM=1 restores the old split.
-    if (M <= 16 || (M <= (options().no_midm ? 64 : 32) && N <= 8192)) return V_SKINNY;
+    // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us vs 18 us tiled); two token tiles while the tiled
+    // grid cannot fill the chip (N <= 8192); three and four token tiles (33 .. 64 tokens) only against narrow matrices (N < 6144) — from 6144 output channels on, the
+    // 64-row ring tiles of round 4 have enough tiles and win (HBM-fed: 64 x 6144 x 4096 17.9 -> 13.2 us, 64 x 28672 x 4096 46.7 -> 31.6; but 64 x 4096 x 4096 10.4 against
+    // 12.7 and 64 x 4096 x 14336 26.3 against 36.3 stay here: profiles/r04_midm_decode.txt).  PQ_NO_MIDM=1: the round-3 split (<= 64 tokens, N <= 8192).
+    if (M <= 16 || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144))) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.

@@ -32,6 +32,7 @@ struct Options {
     bool no_midm = false;            // PQ_NO_MIDM=1: no 64-row ring tiles for 64 < M <= 512 (the round-3 dispatch)
     bool fsk_fenced = false;         // PQ_FSK_FENCED=1: the ticket hand-over with the documented agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) as well
     int fake_cus = 0;                // PQ_FAKE_CUS=n: plan as if the device had n CUs (tests of the residency guard)
+    bool skinny_stage = true;        // PQ_SKINNY_STAGE=0: the weight-streaming kernel with its activation fragments straight from L2 (rounds 1-3)
     int skinny_rb = 0;               // 0 auto, 1 / 2 forced
     int k1_rpw = 0;                  // 0 auto, 1 / 2 forced
     bool k1_st16 = false;            // 16-byte code stores in K1: A/B in profiles/r03_k1_st16.txt

@@ -288,7 +288,7 @@ def test_skinny_gemm_exact(pq, M, N, K, pq_opt):
     """Decode-like shapes (M <= 64) run the weight-streaming kernel: full-range int8 operands, exact int32 accumulators
     (int_mm) and the fused epilogue with bias, all dtypes of output, ragged N and M."""
     from protoquant_amd import _lib
-    if M > 32 and K % 128 == 0:      # 33 .. 64 tokens: the dispatcher prefers the 64-row ring tiles since round 4; the weight-streaming kernel (3 - 4 token tiles) stays covered by force
+    if M > 32 and N >= 6144 and K % 128 == 0:      # 33 .. 64 tokens against wide matrices: the 64-row ring tiles since round 4; the weight-streaming kernel stays covered by force
         assert not _lib.lib().pq_gemm_variant_name(M, N, K, K, K).startswith(b"skinny")
         pq_opt("PQ_FORCE_VARIANT", "skinny")
     assert _lib.lib().pq_gemm_variant_name(M, N, K, K, K) == b"skinny_16x16x64"
@@ -1116,7 +1116,7 @@ def test_errors_are_loud(pq):
     assert st == 1 and b"pq_quant_rowwise" in L.pq_last_error()
 
 
-@pytest.mark.parametrize("M,N,K,want", [(65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
+@pytest.mark.parametrize("M,N,K,want", [(48, 6144, 4096, "ring64x64"), (64, 28672, 4096, "ring64x128"), (64, 4096, 4096, "skinny"), (65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
                                         (384, 4096, 14336, "ring64x128"), (512, 4096, 4096, "ring64x128"), (512, 4096, 14336, "ring64x128"), (500, 4000, 1152, "ring64x128"),
                                         (128, 28672, 4096, "ring128"), (512, 28672, 4096, "sp256"), (1024, 1024, 8192, "ring64x64"), (2048, 1024, 8192, "ring64x128"),
                                         (640, 2048, 4096, "ring64x128"), (4096, 1024, 8192, "ring128")])
