@@ -12,9 +12,10 @@
 
 namespace pq {
 
-// k-steps (64 bytes of K each) loaded per batch: U KiB of weights (+ U*MT KiB of activations) in flight per wave, sized so
-// that 16 waves per workgroup stay within 128 VGPRs
-constexpr int sk_batch(int mt) { return mt == 1 ? 8 : (mt == 2 ? 4 : 2); }
+// k-steps (64 bytes of K each) per batch, sized so that 16 waves per workgroup stay within 128 VGPRs.  One weight block per wave (RB = 1): TWO batches of weights are in
+// registers — the next one is requested before the current one is multiplied, so a wave always has weight bytes in flight (HBM-fed: 1 x 4096 x 4096 7.1 -> 6.7 us,
+// 16 x 4096 x 14336 20.5 -> 18.7).  Two blocks per wave (RB = 2): one batch at a time, as in rounds 1-3 — the pipelined form was 7 % SLOWER there (1 x 28672 x 4096).
+constexpr int sk_batch(int mt, int rb) { return rb == 1 ? (mt == 1 ? 4 : 2) : (mt * rb == 2 ? 4 : 2); }
 
 // RB: 16-row weight blocks per wave.  The direct-to-fragment access pattern (16 segments of 64 B per instruction) tops out
 // near 9.8 TB/s over the whole chip (tools/ubench/l2_ingest), and the activation fragments travel the same path from L2:
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), KS = blockDim.x >> 6;
     const int r = lane & 15, c = lane >> 4;
     const int n0 = blockIdx.x * (16 * RB);
-    constexpr int SK_U = sk_batch(MT * RB);
+    constexpr int SK_U = sk_batch(MT, RB);
 
     // this wave's k-steps: a balanced slice of the K / 64 steps
     const int steps = K >> 6, s0 = (int)((int64_t)steps * w / KS), s1 = (int)((int64_t)steps * (w + 1) / KS);
@@ -67,22 +68,24 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
             xrow[i] = X + (int64_t)m * ldx + lunit * 16;
         }
     }
-    int s = s0;
-    for (; s + SK_U <= s1; s += SK_U) {
-        v4i fw[SK_U][RB], fx[SK_U][MT];
+    // one batch: SK_U k-steps.  RB = 1: the weight fragments of batch s + SK_U are requested BEFORE the MFMAs of batch s (two register sets).
+    auto load_w = [&](v4i (&fw)[SK_U][RB], int sb) {
 #pragma unroll
-        for (int u = 0; u < SK_U; ++u) {
+        for (int u = 0; u < SK_U; ++u)
 #pragma unroll
-            for (int b = 0; b < RB; ++b) fw[u][b] = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)(s + u) * 64);
-            if constexpr (!STAGE) {
+            for (int b = 0; b < RB; ++b) fw[u][b] = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)(sb + u) * 64);
+    };
+    auto compute = [&](const v4i (&fw)[SK_U][RB], int sb) {
+        v4i fx[SK_U][MT];
+        if constexpr (!STAGE) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
-            }
-        }
-        if constexpr (STAGE) {
+            for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(sb + u) * 64);
+        } else {
             v4i xr[NLD];
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) xr[i] = *reinterpret_cast<const v4i*>(xrow[i] + (int64_t)s * 64);
+            for (int i = 0; i < NLD; ++i) xr[i] = *reinterpret_cast<const v4i*>(xrow[i] + (int64_t)sb * 64);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the previous batch's fragment reads have returned: its region may be overwritten
 #pragma unroll
             for (int i = 0; i < NLD; ++i) *reinterpret_cast<v4i*>(stg + (i * RPI + lrow) * RSTR + lunit * 16) = xr[i];
@@ -98,6 +101,44 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
             for (int b = 0; b < RB; ++b)
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[u][b], fx[u][t], acc[b][t], 0, 0, 0);
+    };
+    int s = s0;
+    if constexpr (RB != 1) {            // (rounds 1-3's loop, weight and activation requests interleaved k-step by k-step when the activations come straight from L2)
+        for (; s + SK_U <= s1; s += SK_U) {
+            v4i fw[SK_U][RB];
+            if constexpr (STAGE) {
+                load_w(fw, s);
+                compute(fw, s);
+            } else {
+                v4i fx[SK_U][MT];
+#pragma unroll
+                for (int u = 0; u < SK_U; ++u) {
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) fw[u][b] = *reinterpret_cast<const v4i*>(wp[b] + (int64_t)(s + u) * 64);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) fx[u][t] = *reinterpret_cast<const v4i*>(xp[t] + (int64_t)(s + u) * 64);
+                }
+#pragma unroll
+                for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+                    for (int b = 0; b < RB; ++b)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[u][b], fx[u][t], acc[b][t], 0, 0, 0);
+            }
+        }
+    } else if (s + SK_U <= s1) {
+        v4i fw0[SK_U][RB], fw1[SK_U][RB];
+        load_w(fw0, s);
+        for (;;) {
+            const bool more1 = s + 2 * SK_U <= s1;
+            if (more1) load_w(fw1, s + SK_U);
+            compute(fw0, s); s += SK_U;
+            if (!more1) break;
+            const bool more2 = s + 2 * SK_U <= s1;
+            if (more2) load_w(fw0, s + SK_U);
+            compute(fw1, s); s += SK_U;
+            if (!more2) break;
+        }
     }
     for (; s < s1; ++s) {
         v4i fx[MT];
@@ -166,10 +207,10 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
 }
 
 // KS: enough waves for ~8 per CU overall, at least two k-step batches per wave, at most 16 waves per workgroup
-static int skinny_ks(int64_t blocks, int64_t K, int tiles) {
+static int skinny_ks(int64_t blocks, int64_t K, int mt, int rb) {
     const int64_t steps = K / 64;
     int ks = 1;
-    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(tiles)) ks <<= 1;
+    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(mt, rb)) ks <<= 1;
     return ks;
 }
 // two weight blocks per wave once that still leaves >= 192 workgroups (measured: N = 6144 10.2 -> 8.3 us at 16 tokens, lm_head
@@ -182,11 +223,11 @@ void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t l
     const int mt = (int)((M + 15) / 16);
     const int rb = (mt <= 2 && skinny_rb2(N)) ? 2 : 1;     // (3-4 token tiles x 2 blocks would not fit the register budget)
     const int64_t blocks = (N + 16 * rb - 1) / (16 * rb);
-    const int ks = skinny_ks(blocks, K, mt * rb);
+    const int ks = skinny_ks(blocks, K, mt, rb);
     const dim3 grid((unsigned)blocks), block((unsigned)(ks * 64));
     const bool stage = opt().skinny_stage && M > 1;       // (one token: its 16 "rows" are one clamped row — the direct loads are already cheap)
     const size_t lds_red = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;
-    const size_t lds_stg = stage ? (size_t)ks * mt * 16 * (sk_batch(mt * rb) * 64 + 16) : 0;
+    const size_t lds_stg = stage ? (size_t)ks * mt * 16 * (sk_batch(mt, rb) * 64 + 16) : 0;
     const size_t lds = lds_red > lds_stg ? lds_red : lds_stg;
     // (the staging regions of 16 waves need up to 147 KiB of dynamic LDS: above the 64-KiB default, the limit is raised once per instantiation)
 #define PQ_SK(MTv, RBv) do { if (stage) { static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s8_skinny<OUT, MTv, RBv, true>), \
