@@ -229,9 +229,10 @@ void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t l
     const size_t lds_red = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;
     const size_t lds_stg = stage ? (size_t)ks * mt * 16 * (sk_batch(mt, rb) * 64 + 16) : 0;
     const size_t lds = lds_red > lds_stg ? lds_red : lds_stg;
-    // (the staging regions of 16 waves need up to 147 KiB of dynamic LDS: above the 64-KiB default, the limit is raised once per instantiation)
-#define PQ_SK(MTv, RBv) do { if (stage) { static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s8_skinny<OUT, MTv, RBv, true>), \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)attr_; \
+    // (the staging regions of 16 waves need up to 147 KiB of dynamic LDS: above the 64-KiB default the limit is raised — per launch, a host-side attribute of the
+    // function on the CURRENT device, so a process that drives several devices gets it on each)
+#define PQ_SK(MTv, RBv) do { if (stage) { if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s8_skinny<OUT, MTv, RBv, true>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                                   gemm_s8_skinny<OUT, MTv, RBv, true><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); } \
                              else gemm_s8_skinny<OUT, MTv, RBv, false><<<grid, block, lds, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K); } while (0)
     if (rb == 2) { if (mt == 1) PQ_SK(1, 2); else PQ_SK(2, 2); }
