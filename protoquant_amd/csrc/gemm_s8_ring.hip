@@ -31,17 +31,22 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     constexpr int NMF = 2 * NPI * NQJ, NRD = 2 * (NPI + NQJ);         // MFMAs and fragment reads per K-tile and consumer wave
     constexpr int RPS = (2 * NRD + NMF - 1) / NMF;                    // fragment reads per MFMA shadow: all of them behind the first half of the MFMAs
     constexpr int SLOT = KT * BUF;
-    static_assert(TM % 32 == 0 && TN % 32 == 0 && NB >= 3 && NB * SLOT <= 160 * 1024 && (NB - 1) * KT * PPT <= 31, "ring tile shape");
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && NB >= 3 && NB * SLOT <= 160 * 1024 && (NB - 1) * KT * PPT <= 63, "ring tile shape");
     __shared__ __attribute__((aligned(16))) uint8_t smem[NB * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
     const int w = wave & 3, wp = w >> 1, wq = w & 1;
 
-    // tile assignment: XCD remap (blocks of one XCD get a contiguous run of tiles), then m fastest inside a band of n — the tiles that stream
-    // one weight panel are neighbours on one XCD: the panel comes from HBM once per XCD, the others hit its L2
+    // tile assignment: XCD remap (blocks of one XCD get a contiguous run of tiles), then bands of up to 8 m-tiles with m fastest inside the band (as gemm_s8_ring128): the
+    // tiles that stream one weight panel are neighbours on one XCD — the panel comes from HBM once per XCD, the others hit its L2 — and an XCD's 32 tiles touch 8 activation
+    // + 4 weight panels instead of 32 + 1
     const int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
-    const int tm = t % tiles_m, tn = t / tiles_m;
+    constexpr int GM = 8;
+    const int band = t / (GM * tiles_n);
+    const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
+    const int tin = t - band * GM * tiles_n;
+    const int tm = band * GM + tin % gm, tn = tin / gm;
     const int m0 = tm * TM, n0 = tn * TN;
 
     uint32_t offP[PPW], offQ[QPW];
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     // and the others find it in the XCD's L2 — as long as the chunk of all the panels an XCD works on fits that L2 (4 MiB): a rotation over the whole of a
     // long K turned every re-read into an Infinity-Cache read and made the launch up to 2x slower (512 x 4096 x 14336: 37 -> 73 us).  `ct` is sized by the
     // launcher for ~2 MiB per XCD (ct >= NT: one chunk; rot_div = 0: no rotation).  Integer sums do not depend on the order of the K-tiles: same bits.
-    auto rot_of = [&](int len) { return rot_div > 0 ? (int)(((int64_t)(tm % rot_div) * len) / rot_div) : 0; };
+    auto rot_of = [&](int len) { return rot_div > 0 ? (int)(((int64_t)((tin % gm) % rot_div) * len) / rot_div) : 0; };
     int cbase = 0, clen = ct < NT ? ct : NT;
     int cpos = rot_of(clen), cleft = clen;
     const int8_t* const gP0 = W + (int64_t)n0 * ldw;
@@ -242,11 +247,11 @@ void launch_gemm_ringt(int tile, const int8_t* A, int64_t lda, const int8_t* B, 
     int ct = 0, rd = 0;
     if (tile == 0) {
         const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 127) / 128);
-        rot_plan(tiles_m, 128, &ct, &rd);
+        rot_plan(tiles_m < 8 ? tiles_m : 8, 128, &ct, &rd);
         gemm_s8_ringt<OUT, 64, 128, 3, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd);
     } else {
         const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 63) / 64);
-        rot_plan(tiles_m, 64, &ct, &rd);
+        rot_plan(tiles_m < 8 ? tiles_m : 8, 64, &ct, &rd);
         gemm_s8_ringt<OUT, 64, 64, 4, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd);
     }
 }

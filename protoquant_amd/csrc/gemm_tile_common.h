@@ -18,6 +18,8 @@ __device__ __forceinline__ void wait_vmcnt_lgkm0(int n) {
 #define PQ_W(k) case k: __builtin_amdgcn_s_waitcnt(waitcnt_imm(k, 0)); break;
         PQ_W(0) PQ_W(1) PQ_W(2) PQ_W(3) PQ_W(4) PQ_W(5) PQ_W(6) PQ_W(7) PQ_W(8) PQ_W(9) PQ_W(10) PQ_W(11) PQ_W(12) PQ_W(13) PQ_W(14) PQ_W(15)
         PQ_W(16) PQ_W(17) PQ_W(18) PQ_W(19) PQ_W(20) PQ_W(21) PQ_W(22) PQ_W(23) PQ_W(24) PQ_W(25) PQ_W(26) PQ_W(27) PQ_W(28) PQ_W(29) PQ_W(30) PQ_W(31)
+        PQ_W(32) PQ_W(33) PQ_W(34) PQ_W(35) PQ_W(36) PQ_W(37) PQ_W(38) PQ_W(39) PQ_W(40) PQ_W(41) PQ_W(42) PQ_W(43) PQ_W(44) PQ_W(45) PQ_W(46) PQ_W(47)
+        PQ_W(48) PQ_W(49) PQ_W(50) PQ_W(51) PQ_W(52) PQ_W(53) PQ_W(54) PQ_W(55) PQ_W(56) PQ_W(57) PQ_W(58) PQ_W(59) PQ_W(60) PQ_W(61) PQ_W(62) PQ_W(63)
 #undef PQ_W
         default: __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0)); break;
     }
