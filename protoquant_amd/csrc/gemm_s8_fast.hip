@@ -1077,8 +1077,9 @@ template void launch_splitk_reduce<PQ_F32>(const int32_t*, int, int64_t, int64_t
 // ------------------------------------------------------------------------------------------------
 // gemm_s8_ring128 — 128 x 128 output tile, 4 waves (one per SIMD), wave tile 64(n) x 64(m): the variant for grids that fill
 // at most half the chip with the big tiles (1024-wide shards, M <= 512).  A tile this small needs 64 B/clk/CU of operand
-// ingest; at ~2000 cycles of L2 latency that is 128 KiB in flight per CU, so the design is a 4-deep ring of 32-KiB K-tiles
-// (three in flight while one is read) — the LDS capacity, not the MFMA rate, sets its ceiling (~3/4 of the MFMA rate).
+// ingest to keep its MFMAs fed; at ~2000 cycles of L2 latency that is 128 KiB in flight per CU, so the design is a 4-deep ring of 32-KiB K-tiles
+// (three in flight while one is read).  What it reaches is set by the L2 -> LDS path and the board's power (round 4, profiles/r04_ablate_ring.txt:
+// the DMA stream alone 82 GB/s per CU = 21 TB/s over the chip; the product loop 707 cycles per K-tile at 1.56 GHz; barriers 4.5 %, a fifth slot -4 %).
 // Each wave keeps the fragments of the current K-tile in registers and reads ALL fragments of the next one (16 x
 // ds_read_b128) in the shadows of the current tile's 32 MFMAs; the DMA pieces of tile kt+4 follow in the next shadows.
 // One s_barrier per K-tile.  Same LDS image as the big kernel: [128 rows][128 B], 16-byte chunk c of row r at c ^ ((r>>1)&7).
@@ -1090,10 +1091,22 @@ constexpr int R_TILE = 128, R_NBUF = 4, R_OPER = 128 * FBK /* 16 KiB */, R_BUF =
 // second wave on every SIMD whose only job is the DMA stream: waves 0-3 (consumers) run the pure MFMA + ds_read stream, waves
 // 4-7 (loaders) issue all 32 pieces of a K-tile (8 each) and wait for them; one s_barrier per K-tile joins the two roles
 // exactly where the 4-wave form has its barrier, so the ring protocol (and every result bit) is unchanged.
-template <int OUT, bool LC = false>
+template <int OUT, bool LC = false, int ABL = 0>   // ABL (dev builds, timing only): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs, 8 no barriers in the loop, 16 stamps around the consumers' K-loop
 __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
-                                                       int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div) {
+                                                       int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div,
+                                                       unsigned long long* stamps) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[R_LDS];
+    auto stamp = [&](int point) {     // dev builds (ABL & 16): consumer waves stamp {100 MHz counter, shader cycles} around their K-loop
+        if constexpr ((ABL & 16) != 0) {
+            if (stamps != nullptr) {
+                const unsigned long long r = __builtin_amdgcn_s_memrealtime(), c = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
+                    unsigned long long* d = stamps + (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + point) * 2;
+                    d[0] = r; d[1] = c;
+                }
+            }
+        }
+    };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = LC && wave >= 4;                                 // (4-wave form: every wave loads and computes)
@@ -1200,14 +1213,15 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
                     if (rem >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 15));
                     else if (rem == 2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(8, 15));
                     else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
-                    __builtin_amdgcn_s_barrier();
+                    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
                 }
-                if (rem >= R_NBUF) static_for<8>([&](auto gc) { dma_item(kt & 3, gc); });
+                if constexpr (!(ABL & 1)) if (rem >= R_NBUF) static_for<8>([&](auto gc) { dma_item(kt & 3, gc); });
             }
             return;
         }
     }
     static_for<16>([&](auto ic) { read_item(0, fa, ic); });
+    stamp(0);
 
     // one K-tile: 32 MFMAs on `cur`; in their shadows the 16 fragment reads of tile kt+1 into `nxt`, then the 8 DMA pieces
     // of tile kt+4 into the ring slot tile kt just vacated (its fragments are in registers; every wave passed the barrier
@@ -1220,7 +1234,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
             else if (rem >= 3) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
             else if (rem == 2) __builtin_amdgcn_s_waitcnt(0x0078); // vmcnt(8)  lgkmcnt(0)
             else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0)  lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         }
         const int nbuf = ((kt + 1) & 3) * R_BUF;
         const bool more = rem >= R_NBUF;                      // tile kt+4 exists
@@ -1231,10 +1245,11 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
             // the two register files and pays 4 v_accvgpr_write + s_nop in front of every other MFMA (measured 44 % -> see DESIGN)
             // (LC: two waves per SIMD share a 256-register budget, which hipcc halves as soon as a kernel names AGPRs — the builtin
             // keeps all of it as arch VGPRs, as in the big kernel)
-            if constexpr (LC) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur[ks * 4 + i], cur[8 + ks * 4 + j], acc[i][j], 0, 0, 0);
+            if constexpr (ABL & 4) { if constexpr (x == 0) asm volatile("" : "+v"(cur[0]), "+v"(cur[8])); }
+            else if constexpr (LC) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur[ks * 4 + i], cur[8 + ks * 4 + j], acc[i][j], 0, 0, 0);
             else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[ks * 4 + i]), "v"(cur[8 + ks * 4 + j]));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (x < 16) read_item(nbuf, nxt, xc);      // (last tile: reads a stale slot, values unused)
+            if constexpr (x < 16 && !(ABL & 2)) read_item(nbuf, nxt, xc);      // (last tile: reads a stale slot, values unused)
             else if constexpr (x < 24 && !LC) { if (more) dma_item(kt & 3, std::integral_constant<int, x - 16>{}); }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1242,6 +1257,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     int kt = 0;
     for (; kt + 1 < NT; kt += 2) { tile(kt, fa, fb); tile(kt + 1, fb, fa); }
     if (kt < NT) tile(kt, fa, fb);
+    stamp(1);
 
     // the asm MFMAs are invisible to hipcc's hazard tracking: drain the pipe, then pass every accumulator through an empty
     // asm so that no v_accvgpr_read can be scheduled above the drain
@@ -1322,8 +1338,19 @@ void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t 
     const int gmx = tiles_m < 8 ? tiles_m : 8;
     const int rot_div = (opt().ring_rot && N * K >= (6 << 20)) ? gmx : 0;      // weight streams that matter: below ~6 MiB the rotation only costs (4096 x 512 x 8192: -5 %)
     const int ct = opt().ring_rot > 1 ? opt().ring_rot : rot_chunk_ktiles(gmx, 128);
-    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div);
-    else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1 << 30, 0);
+#ifdef PQ_ABLATION_BUILD
+    if constexpr (OUT == PQ_BF16) {
+        switch (gemm_debug_flags()) {
+#define PQ_RABL(n) case n: gemm_s8_ring128<OUT, true, n><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div, g_stamps); return;
+            PQ_RABL(1) PQ_RABL(2) PQ_RABL(3) PQ_RABL(4) PQ_RABL(5) PQ_RABL(6) PQ_RABL(7) PQ_RABL(8) PQ_RABL(9) PQ_RABL(10) PQ_RABL(11) PQ_RABL(14)
+            PQ_RABL(16) PQ_RABL(17) PQ_RABL(18) PQ_RABL(19) PQ_RABL(20) PQ_RABL(22) PQ_RABL(24)
+#undef PQ_RABL
+            default: break;
+        }
+    }
+#endif
+    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div, nullptr);
+    else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1 << 30, 0, nullptr);
 }
 template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

@@ -1,10 +1,11 @@
 // gemm_s8_ring.hip — K3/K4 for SMALL GRIDS: 33 .. 512 tokens (short prefill chunks, speculative / batched decode) and any other problem whose 128 x 128 ring tiles
 // (gemm_s8_ring128) would fill well under the 256 CUs: y[M, N] = dequant(xq[M, K] . wq[N, K]^T) on 64(m) x 128(n) or 64 x 64 tiles, one per CU on every CU.
 //
-// What bounds the regime: neither the matrix pipe nor HBM but the LDS and the L2 -> CU path.  A tile of tm x tn rows moves (tm + tn) x 128 bytes into the
-// LDS per K-tile (LDS-DMA) and reads twice that back as MFMA fragments (four consumer waves, 2 x 2 over the tile: every byte is read by two of them): 3 LDS bytes per ingested
-// byte at 128 B/clk — 384 cycles per K-tile for a 64 x 64 tile against 128 of MFMA (measured ~400), 576 for 64 x 128 (~680), 768 for the 128 x 128 ring tile (~720) — and a CU
-// ingests ~50 B/clk (26 TB/s over the chip: profiles/r01_ubench_l2_ingest.txt).  M = 512 x N = 4096 makes only 128 tiles of 128 x 128: half the chip at the LDS-bound rate.
+// What bounds the regime (profiles/r04_ablate_ring.txt, r04_pmc_ring_tiles.txt): neither the matrix pipe nor HBM but the L2 -> CU path.  A tile of tm x tn
+// rows ingests (tm + tn) x 128 bytes per K-tile by LDS-DMA for tm x tn x 128 multiply-adds — 16 KiB per 128 MFMA-cycles for a 64 x 64 tile, four times the bytes per operation
+// of the 256 x 256 tile — and a CU ingests ~50 B/clk (26 TB/s over the chip: profiles/r01_ubench_l2_ingest.txt): ~330 cycles per K-tile for 64 x 64 (measured ~400), ~490 for
+// 64 x 128 (~680); the 128 x 128 ring tile runs its DMA stream alone at 21 TB/s and the whole loop at a power-limited 1.56 GHz.  M = 512 x N = 4096 makes only 128 tiles of
+// 128 x 128: half the chip at that rate.
 // Splitting K over workgroups (the fused hand-over of the big tile) costs ~3 - 4 us of store -> ticket -> load latency, as much as it saves on a 10-us launch.  So this kernel
 // goes the other way: smaller tiles on EVERY CU, with the loader / consumer structure of the ring tile, rings of 3 slots x 2 K-tiles x 24 KiB / 4 x 2 x 16 KiB (one barrier per
 // slot) and a K walk rotated between the workgroups that share a weight panel (below).  The dispatcher (pq_api.hip: pick_variant) chooses between the three ring tiles by
