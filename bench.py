@@ -68,6 +68,11 @@ def parse():
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--native-timeout", type=float, default=120.0,
+                    help="tp over RCCL with > 1 rank: seconds the native exchange path (libpq_rccl.so, graph-captured) may take before the line measured "
+                         "with torch.distributed's all-gather just before is printed instead (a multi-GPU run is never lost to a hung collective)")
+    ap.add_argument("--safety-net", action="store_true", help="take the torch.distributed measurement + watchdog also at 1 rank (tests)")
+    ap.add_argument("--simulate-native-hang", action="store_true", help="tests: the native path never returns (the watchdog must print the safe line)")
     return ap.parse_args()
 
 
@@ -696,7 +701,7 @@ def main():
     tp = mode == "tp"
     st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
 
-    def build_step(tp_mode):
+    def build_step(tp_mode, force_torch=False):
         """(step_fn, k1_fn, gemm_fn, gather_fn or None, n_local, state) for one rank"""
         lo, hi = shard_bounds(N, world, rank) if tp_mode else (0, N)
         n_local = hi - lo
@@ -723,7 +728,7 @@ def main():
         if tp_mode:
             y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
             rg = None
-            if args.backend == "nccl" and not args.torch_gather:
+            if args.backend == "nccl" and not args.torch_gather and not force_torch:
                 try:                                   # the native exchange; a failure to bootstrap it must not lose the measurement
                     from protoquant_amd.sharded import RcclColumnGather
                     rg = RcclColumnGather()
@@ -748,13 +753,82 @@ def main():
                     y_full.copy_(gather_columns(y, N))
         return k1, k3, gather, n_local, info, (x, xq, xs, y, wq, ws, wsp)
 
-    k1, k3, gather, n_local, xinfo, _keep = build_step(tp)
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- safety net (tp over RCCL with more than one rank): the native exchange — a second communicator inside libpq_rccl.so, captured into the step's hipGraph —
+    # has never run on more than one GPU in the builder's hands.  A collective that hangs cannot be cancelled from inside the process, so BEFORE it is tried the
+    # same step is measured with torch.distributed's own all-gather, issued eagerly (the path every PyTorch job uses); a watchdog prints THAT line and ends
+    # the rank with status 0 if the native path has not produced its line within --native-timeout seconds.  The line says which one it is (`config.exchange`, `fallback`).
+    import threading
+    net = {"lock": threading.Lock(), "done": False, "line": None, "timer": None}
+    if tp and args.backend == "nccl" and not args.torch_gather and (world > 1 or args.safety_net):
+        try:
+            k1s, k3s, gathers, nls, infos, _keeps = build_step(True, force_torch=True)
+            gs_ = graph_of(lambda: (k1s(), k3s()), 1)
+            gk_ = graph_of(k3s, 20)
+            Ks = max(1, args.steps)
+            for _ in range(max(args.warmup, 20)):
+                gs_.replay(); gathers()
+            fence()
+            bl = []
+            for _ in range(5):
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(Ks):
+                    gs_.replay(); gathers()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                bl.append(float(tt.item()))
+            bl.sort()
+            sdt = bl[len(bl) // 2]
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gk_.replay(); torch.cuda.synchronize()
+            a_.record(); gk_.replay(); b_.record(); b_.synchronize()
+            tg = a_.elapsed_time(b_) * 1e3 / 20
+            net["line"] = {
+                "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
+                "value": round(2.0 * M * N * K * Ks / sdt / 1e12, 2), "unit": "TOPS", "n_gpus": world, "steps": Ks, "warmup": args.warmup,
+                "ms_per_step": round(sdt / Ks * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+                "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
+                           "parallelism": f"tp{world}: W column-sharded ({nls} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant",
+                           "launch": "hipgraph x1 step/replay, collective eager behind each step", "collective_in_graph": False, "repeats": 5,
+                           "timed": f"median of 5 blocks of exactly {Ks} steps (barrier + synchronize around each block, max over ranks)", **infos},
+                "ms_per_step_min": round(bl[0] / Ks * 1e3, 5), "ms_per_step_max": round(bl[-1] / Ks * 1e3, 5),
+                "roofline": {"bound": "mfma", "kernel": lib.pq_gemm_variant_name(M, nls, K, K, K).decode(), "achieved": round(2.0 * M * nls * K / tg / 1e6, 1), "peak": PEAK_INT8_TOPS,
+                             "unit": "TOP/s", "frac": round(2.0 * M * nls * K / tg / 1e6 / PEAK_INT8_TOPS, 4), "avg_kernel_us": round(tg, 2),
+                             "how": "one hipGraph replay of 20 back-to-back launches of the rank's shard GEMM, HIP events on the launch stream", "traffic": None},
+                "cpu_baseline": None,
+                "fallback": f"the native exchange (libpq_rccl.so, captured into the step graph) did not produce its line within {args.native_timeout:.0f} s: "
+                            "this is the same step with torch.distributed's all-gather, measured before the native path was tried",
+            }
+            del gs_, gk_, k1s, k3s, gathers, _keeps
+        except Exception as e:      # the net must never cost the run
+            print(f"[bench] safety-net measurement failed ({e}); continuing without it", file=sys.stderr)
+
+        def fire():
+            with net["lock"]:
+                if net["done"]:
+                    return
+                net["done"] = True
+                print(f"[bench] rank {rank}: the native RCCL path did not finish within {args.native_timeout:.0f} s — "
+                      + ("printing the torch.distributed line" if net["line"] else "no safe line either"), file=sys.stderr)
+                if rank == 0 and net["line"] is not None:
+                    emit_json(net["line"])
+                sys.stderr.flush()
+                os._exit(0 if net["line"] is not None else 3)
+        net["timer"] = threading.Timer(args.native_timeout, fire)
+        net["timer"].daemon = True
+        net["timer"].start()
+        if args.simulate_native_hang:
+            while True:
+                time.sleep(1.0)
+
+    k1, k3, gather, n_local, xinfo, _keep = build_step(tp)
 
     # ---- the step.  Everything is replayed from a hipGraph of S steps (host-independent): K1 + K3/K4 and, in a tp step, the exchange as
     # well — RCCL collectives are capturable, and a ~60 us step issued collective by collective from Python would time the host, not
@@ -1087,8 +1161,16 @@ def main():
         out["cpu_baseline"] = cpu_baseline(M, N, K)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        emit_json(out)
+    with net["lock"]:
+        if net["done"]:            # the watchdog has spoken for this rank (it is about to end the process)
+            return
+        net["done"] = True
+        if net["timer"] is not None:
+            net["timer"].cancel()
+        if rank == 0:
+            if net["line"] is not None:
+                out["torch_distributed_exchange_ms_per_step"] = net["line"]["ms_per_step"]       # the safety net's figure, beside the native one
+            emit_json(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -125,3 +125,37 @@ def test_bench_tp_step_is_one_graph_world1():
     assert line["host_bound"] is False and line["exchange_us"] > 0 and line["compute_us"] > 0
     assert line["ms_per_step"] * 1e3 >= 0.9 * line["compute_us"]                 # the exchange is in the step
     assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True
+
+
+def _bench_tp(extra, port):
+    env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3", "--warmup-seconds", "0.3",
+                        "--no-cpu-baseline", "--no-gpu-context", "--no-dp-leg", "--safety-net", *extra], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_tp_safety_net_prints_the_torch_distributed_line_when_the_native_path_hangs():
+    """A multi-GPU run must never be lost to a hung collective: before the native exchange (a second RCCL communicator, captured into the step graph) is tried,
+    bench.py measures the same step with torch.distributed's all-gather; if the native path does not produce its line in time, a watchdog prints that one and the
+    rank exits 0.  Here the hang is simulated (the native phase never returns)."""
+    r, lines = _bench_tp(["--simulate-native-hang", "--native-timeout", "8"], "29565")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "fallback" in line and line["config"]["collective_in_graph"] is False and line["config"]["exchange"].startswith("torch.distributed")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] > 0 and line["scaling"] == "strong" and line["roofline"]["frac"] > 0.2
+    assert "did not finish" in r.stderr
+
+
+def test_bench_tp_safety_net_stays_silent_when_the_native_path_finishes():
+    r, lines = _bench_tp([], "29566")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "fallback" not in line and line["config"]["collective_in_graph"] is True
+    assert line["torch_distributed_exchange_ms_per_step"] > 0
