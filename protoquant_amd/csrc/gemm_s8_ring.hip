@@ -66,8 +66,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
         offQ[jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
     }
     const int NT = K / FBK;
-    // K ROTATION in chunks: the tiles_m workgroups that stream one weight panel (neighbours on one XCD, started together) walk each chunk of `ct` K-tiles
-    // from DIFFERENT starting points, len * tm / tiles_m apart, wrapping inside the chunk.  In lockstep they would all ask for the same weight bytes at
+    // K ROTATION in chunks: the up-to-8 workgroups of a band that stream one weight panel (neighbours on one XCD, started together) walk each chunk of `ct` K-tiles
+    // from DIFFERENT starting points, len / rot_div apart (rot_div = min(tiles_m, 8), from the launcher), wrapping inside the chunk.  In lockstep they would all ask for the same weight bytes at
     // the same time: the panel's unique bytes in flight — what HBM bandwidth is made of — would be ONE workgroup's ring however many workgroups there are
     // (measured, weights from HBM: 512 x 4096 x 14336 at 1.15 TB/s).  Rotated, every workgroup's ring holds different bytes; each byte comes from HBM once
     // and the others find it in the XCD's L2 — as long as the chunk of all the panels an XCD works on fits that L2 (4 MiB): a rotation over the whole of a
