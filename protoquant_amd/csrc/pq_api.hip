@@ -183,9 +183,8 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // on operand ingest, ~2/3 of the 128 x 256 tile's rate per CU, but twice the blocks and no slab traffic).  Measured:
     // k/v 4096x1024x4096 31 -> 24 us, 70B q/o shard 47 (split-K) -> 40 us, 70B down shard 124 (split-K) -> 119 us.
     if (t128 <= 128 && t128sq > t128) {
-        // 64 < M <= 512 (gemm_s8_ring.hip): when the 128 x 128 ring tiles fill well under the chip, SMALLER tiles on every CU — the regime is bound by the L2 -> CU path and
-        // the LDS (a small tile moves 3 bytes through the LDS per byte it ingests), and a K split over workgroups costs as much hand-over latency as it saves on launches
-        // this short.  Rounds of the 256 CUs x the measured time of one tile relative to the 128 x 128 ring tile (K = 4096: 14.0 / 13.4 / 9.2 us; profiles/r04_midm.txt);
+        // 64 < M <= 512 (gemm_s8_ring.hip): when the 128 x 128 ring tiles fill well under the chip, SMALLER tiles on every CU — the regime is bound by the L2 -> CU path
+        // (profiles/r04_ablate_ring.txt), and a K split over workgroups costs more hand-over than it saves on launches this short (measured: profiles/r04_midm_fsk.txt).  Rounds of the 256 CUs x the measured time of one tile relative to the 128 x 128 ring tile (K = 4096: 14.0 / 13.4 / 9.2 us; profiles/r04_midm.txt);
         // PQ_NO_MIDM=1 restores the round-3 dispatch.
         if (!options().no_midm && options().force_splitk <= 1 && options().fsk <= 1) {      // (a forced slice count — experiments, tests — means the split-K forms)
             auto rounds = [](int64_t tiles) { return (double)((tiles + 255) / 256); };
