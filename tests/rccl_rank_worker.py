@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_multirank.py: ONE rank of a multi-GPU job (one process per GPU, RANK / WORLD_SIZE / MASTER_* from the
+"""Child process of tests/test_zz_gpu_real_ranks.py: ONE rank of a multi-GPU job (one process per GPU, RANK / WORLD_SIZE / MASTER_* from the
 environment, gloo for the bootstrap, libpq_rccl.so for the data path).  Every rank holds the full weights, so each result is checked
 locally against the unsharded qlinear — bit for bit for the gathers, and for the reduce-scatter at two ranks (a two-term f32 sum has
 one order).  Prints 'OK <rank>' on success; any assertion kills the job (the parent checks every rank's output)."""
