@@ -189,3 +189,22 @@ def test_persistent_multi_round_kernel_matches(pq, pq_opt):
         assert torch.equal(ya.view(torch.int16), yb.view(torch.int16)), (M, N, K, "bf16")
         assert torch.equal(fa.view(torch.int32), fb.view(torch.int32)), (M, N, K, "f32")
         assert torch.equal(ia, ib), (M, N, K, "int32")
+
+
+@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 22016, 4096), (4096, 1024, 28672), (4096, 1280, 8192), (512, 4096, 4096), (64, 6144, 4096), (16, 28672, 4096)])
+def test_whole_accumulator_equals_torch_int_mm_on_this_gpu(shape):
+    """EVERY int32 accumulator of a full-size problem against an implementation that shares no code with this library: torch._int_mm on the same GPU
+    (hipBLASLt's int8 GEMM).  Integer sums have one right answer; the sampled-row checks against the HOST torch._int_mm above pin the contract's named
+    primitive, this pins the rest of the output to it.  Full-range operands (-128 .. 127)."""
+    import protoquant_amd as pq
+    M, N, K = shape
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    got = pq.int_mm(a, b)
+    if M <= 16:                       # torch._int_mm wants more than 16 rows: pad the activation
+        ap = torch.zeros((32, K), dtype=torch.int8, device="cuda"); ap[:M] = a
+        want = torch._int_mm(ap, b.t())[:M]
+    else:
+        want = torch._int_mm(a, b.t())
+    assert want.dtype == torch.int32 and torch.equal(got, want)
