@@ -208,3 +208,27 @@ def test_whole_accumulator_equals_torch_int_mm_on_this_gpu(shape):
     else:
         want = torch._int_mm(a, b.t())
     assert want.dtype == torch.int32 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 4096, 11008), (4096, 1024, 8192), (256, 4096, 4096), (48, 4096, 14336)])
+def test_whole_output_equals_the_epilogue_in_stock_torch_ops(shape, dtype):
+    """EVERY output element of full-size problems, all three output types, with bias: the fused epilogue against QSPEC E1-E4 written in stock torch ops on the GPU
+    over torch._int_mm's accumulator — two f32 multiplies, one add, one RNE cast: nothing there that torch-ROCm rounds differently from the CPU (its division does;
+    the epilogue has none).  The hashes of tests/golden/fullsize_hashes.json pin bf16 outputs to the CPU pipeline; this extends the whole-output check to fp16 / f32."""
+    import protoquant_amd as pq
+    M, N, K = shape
+    g = torch.Generator(device="cuda"); g.manual_seed(M * 3 + N + K)
+    a = (torch.randn((M, K), device="cuda", generator=g) * 30).round().clamp(-127, 127).to(torch.int8)
+    b = (torch.randn((N, K), device="cuda", generator=g) * 30).round().clamp(-127, 127).to(torch.int8)
+    xs = torch.rand(M, device="cuda", generator=g) * 0.02 + 1e-3
+    ws = torch.rand(N, device="cuda", generator=g) * 0.002 + 1e-4
+    bias = torch.randn(N, device="cuda", generator=g).to(dtype)
+    y = pq.qlinear_s8(a, xs, b, ws, bias, dtype)
+    ap = a
+    if M <= 16:
+        ap = torch.zeros((32, K), dtype=torch.int8, device="cuda"); ap[:M] = a
+    acc = torch._int_mm(ap, b.t())[:M]
+    ref = ((acc.float() * xs[:, None]) * ws[None, :] + bias.float()[None, :]).to(dtype)
+    view = torch.int16 if dtype != torch.float32 else torch.int32
+    assert torch.equal(y.view(view), ref.view(view))
