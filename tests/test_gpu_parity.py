@@ -1145,3 +1145,31 @@ def test_mid_m_regime_exact(pq, M, N, K, want, pq_opt):
             y3 = pq.qlinear_s8(ta, txs, tb, tws, to_gpu(bv, code), TD[code])
             pq_opt("PQ_NO_MIDM", "")
             assert torch.equal(y.view(torch.int16), y3.view(torch.int16)), "mid-M tiles vs the round-3 dispatch"
+
+
+@pytest.mark.parametrize("M,N,K", [(0, 64, 128), (33, 0, 128), (0, 0, 128), (17, 40, 0), (0, 40, 0), (300, 520, 0)])
+def test_empty_problems(pq, M, N, K):
+    """Empty inputs: no rows, no output channels, or an empty reduction (K = 0: every accumulator is 0, y = 0 * xs * ws (+ bias) like the oracle's) — through the int32
+    twin, the fused qlinear (both orientations), the one-call dynamic form and the module with an empty batch."""
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device="cuda")
+    b = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda")
+    xs = torch.rand(M, device="cuda") + 0.5; ws = torch.rand(N, device="cuda") + 0.5
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    acc = pq.int_mm(a, b)
+    assert acc.shape == (M, N) and acc.dtype == torch.int32 and not bool(acc.any())
+    want = Q.epilogue(np.zeros((M, N), np.int32), xs.cpu().numpy(), ws.cpu().numpy(), bits(bias), 0)
+    y = pq.qlinear_s8(a, xs, b, ws, bias, torch.bfloat16)
+    assert y.shape == (M, N)
+    same(y, want, "y")
+    yt = pq.qlinear_s8_t(a, xs, b, ws, bias, torch.bfloat16)
+    assert yt.shape == (N, M)
+    same(yt.t().contiguous(), want, "y^T")
+    if K > 0:
+        lin = torch.nn.Linear(K, max(N, 1), bias=True, device="cuda", dtype=torch.bfloat16)
+        m = pq.qlinear.from_linear(lin)
+        assert m(torch.empty((0, K), dtype=torch.bfloat16, device="cuda")).shape == (0, max(N, 1))
+        assert m(torch.empty((2, 0, K), dtype=torch.bfloat16, device="cuda")).shape == (2, 0, max(N, 1))
+        x = torch.randn((M, K), device="cuda").to(torch.bfloat16)
+        qw = pq.quantize(torch.randn((max(N, 1), K), device="cuda").to(torch.bfloat16))
+        yd = pq.qlinear_dyn(x, qw.int_data, qw.scale, None)
+        assert yd.shape == (M, max(N, 1))
