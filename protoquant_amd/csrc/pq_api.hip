@@ -77,7 +77,7 @@ thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
     const int iv = set ? atoi(value) : 0;
@@ -100,6 +100,8 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_RING_LC")) o.ring_lc = !(set && *value == '0');
     else if (!strcmp(name, "PQ_RING_ROT")) o.ring_rot = !set ? 1 : (iv < 0 ? 0 : iv);
     else if (!strcmp(name, "PQ_K1_LDS")) o.k1_lds = iv < 0 ? 0 : (iv > 65536 ? 65536 : iv);
+    else if (!strcmp(name, "PQ_K2_BLOCKS_A")) o.k2_blocks_a = iv > 0 ? iv : 0;
+    else if (!strcmp(name, "PQ_K2_BLOCKS_E")) o.k2_blocks_e = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
     else if (!strcmp(name, "PQ_K1_RPW")) o.k1_rpw = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
     else if (!strcmp(name, "PQ_SKINNY_STAGE")) o.skinny_stage = !(set && *value == '0');

@@ -2,6 +2,7 @@
 // All three are HBM-bound byte movers: 16-byte coalesced loads, one read of x for K1 (the row lives
 // in registers between the amax reduction and the encode), wavefront shuffles + one LDS hop for the
 // reductions.  Arithmetic follows QSPEC v2 exactly (true fp32 division, RNE, no contraction).
+#include <type_traits>
 #include "quant_device.h"
 
 namespace pq {
@@ -185,58 +186,114 @@ __global__ __launch_bounds__(256) void quant_rowwise_generic(const void* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: reduction along the strided axis.  Launch 1: column amax (bit patterns of non-negative floats
-// order like unsigned ints -> atomicMax on uint32) into `scale`; launch 2: encode with the per-column
-// scale (division-free exact quotient when every column of the wave allows it); launch 3:
-// scale[c] = scale_of(amax[c]) in place.  Loads are unrolled 4 rows deep (independent, clamped addresses).
-constexpr int kColUnroll = 8;     // independent row loads per thread per iteration (bytes in flight)
+// K2: reduction along the strided axis, two passes over x (the second one finds a weight-sized matrix in the Infinity Cache).
+//   pass 1 (col_amax): per-column max |x| on the raw bit patterns (integer max: two columns per v_pk_max_u16 for 16-bit types; a NaN pattern sorts above Inf,
+//     so it propagates), merged across the block's four waves in LDS and across blocks by atomicMax on the f32 bit pattern.  `scale` is the scratch: while it
+//     holds an AMAX the word carries the sign bit (0x80000000 | bits — the unsigned order is unchanged; the memset writes 0x80000000 = "amax 0").
+//   pass 2 (col_encode): every block decodes the word — sign set: s = scale_of(amax); sign clear: it already is the final scale, written by the row-block-0
+//     workgroup of that column strip while this one was still reading (both give the same s: the race is benign by construction) — and encodes with the per-column
+//     exact quotient (division-free when every column of the wave allows it); the blockIdx.x == 0 workgroups store the final scales.  No third launch.
+// Loads are unrolled kColUnroll rows deep (independent, clamped addresses): bytes in flight are what an HBM-bound column walk is made of.
+constexpr int kColUnroll = 8;      // encode: independent row loads per thread per iteration
+constexpr int kAmaxUnroll = 8;     // amax: raw 16-byte vectors only; 16 waves x 8 KiB in flight per workgroup
+constexpr uint32_t kAmaxTag = 0x80000000u;
 
+__device__ __forceinline__ float col_scale_of_word(uint32_t u) {
+    return (u & kAmaxTag) ? scale_of(__builtin_bit_cast(float, u & 0x7FFFFFFFu)) : __builtin_bit_cast(float, u);
+}
+
+// pass 1.  VEC: 16 waves per workgroup; a wave-instruction reads EIGHT rows of an 8-vector column strip (128 bytes: one line per row).  Narrow strips and big
+// workgroups mean few row splits per column for the same bytes in flight, and every row split of a column is one more device-scope atomic on the same word — they
+// serialise at the memory side (with 64-lane strips and 64 row splits the atomics alone took ~10 us of a 28-us K2 at 4096 x 4096).  grid = (row splits, 8-vector strips).
+constexpr int kAmaxWaves = 16;
 template <int DT, bool VEC>
-__global__ __launch_bounds__(256) void col_amax(const uint8_t* __restrict__ x, int64_t rows, int64_t ncolv,
-                                                int64_t ldx_bytes, uint32_t* __restrict__ amax_bits, int rows_per_block) {
+__global__ __launch_bounds__(64 * kAmaxWaves) void col_amax(const uint8_t* __restrict__ x, int64_t rows, int64_t ncolv,
+                                                            int64_t ldx_bytes, uint32_t* __restrict__ amax_bits, int rows_per_block) {
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t cvr = (int64_t)blockIdx.y * 64 + lane;          // rows ride on grid.x (2^31 blocks), columns on grid.y
-    const int64_t cv = cvr < ncolv ? cvr : ncolv - 1;            // clamped: duplicates do not change a max
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    // VEC: strips ride on grid.x (2^31 workgroups: any width), the few row splits on grid.y; scalar fallback: rows on grid.x, 64-column strips on grid.y
+    const int64_t r0 = (int64_t)(VEC ? blockIdx.y : blockIdx.x) * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float m[EPV];
+    if constexpr (VEC) {
+        const int sub = lane & 7, rsub = lane >> 3;
+        const int64_t cvr = (int64_t)blockIdx.x * 8 + sub;
+        const int64_t cv = cvr < ncolv ? cvr : ncolv - 1;        // clamped: duplicates do not change a max
+        const uint8_t* col = x + cv * 16;
+        v4u m = {0u, 0u, 0u, 0u};                                 // per 32-bit word: one f32 magnitude, or two 16-bit magnitudes
+        for (int64_t r = r0 + w * 8 + rsub; r < r1; r += 8 * kAmaxWaves * kAmaxUnroll) {
+            v4u raw[kAmaxUnroll];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) m[j] = 0.0f;
-    const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
-    for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
-        float f[kColUnroll][EPV];
+            for (int u = 0; u < kAmaxUnroll; ++u) {
+                const int64_t rr = r + 8 * kAmaxWaves * u < r1 ? r + 8 * kAmaxWaves * u : r1 - 1;
+                raw[u] = *reinterpret_cast<const v4u*>(col + rr * ldx_bytes);
+            }
 #pragma unroll
-        for (int u = 0; u < kColUnroll; ++u) {
-            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
-            const uint8_t* p = col + rr * ldx_bytes;
-            if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
-            else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
+            for (int u = 0; u < kAmaxUnroll; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (DT == PQ_F32) { const uint32_t a = raw[u][i] & 0x7FFFFFFFu; m[i] = a > m[i] ? a : m[i]; }
+                    else m[i] = pk_max_u16(m[i], raw[u][i] & 0x7FFF7FFFu);
+                }
         }
+        auto merge = [&](const v4u& o) {
 #pragma unroll
-        for (int u = 0; u < kColUnroll; ++u)
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (DT == PQ_F32) m[i] = o[i] > m[i] ? o[i] : m[i];
+                else m[i] = pk_max_u16(m[i], o[i]);
+            }
+        };
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) m[j] = amax_step(m[j], f[u][j]);
-    }
-    __shared__ float part[4][64][EPV];
+        for (int off = 8; off <= 32; off <<= 1) {                 // the eight row groups of the wave
+            v4u o;
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) part[w][lane][j] = m[j];
-    __syncthreads();
-    if (w == 0 && cvr < ncolv) {
+            for (int i = 0; i < 4; ++i) o[i] = (uint32_t)__shfl_xor((int)m[i], off, 64);
+            merge(o);
+        }
+        __shared__ v4u part[kAmaxWaves][8];
+        if (rsub == 0) part[w][sub] = m;
+        __syncthreads();
+        if (w == 0 && rsub == 0 && cvr < ncolv) {
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            float a = m[j];
+            for (int ww = 1; ww < kAmaxWaves; ++ww) merge(part[ww][sub]);
 #pragma unroll
-            for (int ww = 1; ww < 4; ++ww) a = amax_merge(a, part[ww][lane][j]);
-            atomicMax(&amax_bits[cv * EPV + j], __builtin_bit_cast(uint32_t, a));
+            for (int j = 0; j < EPV; ++j) {
+                uint32_t fb;                                     // the column's max |x| as an f32 bit pattern (a NaN stays a NaN: it sorts above Inf)
+                if constexpr (DT == PQ_F32) fb = m[j];
+                else fb = __builtin_bit_cast(uint32_t, amax_bits_to_f32<DT>((m[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+                atomicMax(&amax_bits[cv * EPV + j], kAmaxTag | fb);
+            }
+        }
+    } else {
+        const int64_t cvr = (int64_t)blockIdx.y * 64 + lane;
+        const int64_t cv = cvr < ncolv ? cvr : ncolv - 1;
+        const uint8_t* col = x + cv * Elem<DT>::kBytes;
+        float m = 0.0f;
+        for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
+            float f[kColUnroll];
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) {
+                const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+                f[u] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(col + rr * ldx_bytes));
+            }
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) m = amax_step(m, f[u]);
+        }
+        __shared__ float part[4][64];
+        part[w][lane] = m;
+        __syncthreads();
+        if (w == 0 && cvr < ncolv) {
+            float a = m;
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) a = amax_merge(a, part[ww][lane]);
+            atomicMax(&amax_bits[cv], kAmaxTag | __builtin_bit_cast(uint32_t, a));
         }
     }
 }
 
 template <int DT, bool VEC>
 __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x, int64_t rows, int64_t ncolv,
-                                                  int64_t ldx_bytes, const float* __restrict__ amax,
+                                                  int64_t ldx_bytes, uint32_t* scale_io,
                                                   int8_t* __restrict__ q, int64_t ldq, int rows_per_block) {
     constexpr int EPV = VEC ? 16 / Elem<DT>::kBytes : 1;
     using S = typename Elem<DT>::store_t;
@@ -246,53 +303,88 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     const int64_t cv = live ? cvr : ncolv - 1;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
+    // the first batch of rows is requested BEFORE the scale words are read (two dependent trips to memory would otherwise open every workgroup, and a
+    // workgroup of a weight-sized matrix lives for only two or three batches); from then on the next batch is in flight while the current one is encoded
+    using Raw = typename std::conditional<VEC, v4u, S>::type;
+    auto load_batch = [&](int64_t r, Raw (&raw)[kColUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kColUnroll; ++u) {
+            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+            raw[u] = *reinterpret_cast<const Raw*>(col + rr * ldx_bytes);
+        }
+    };
+    Raw bufA[kColUnroll], bufB[kColUnroll];
+    int64_t r = r0 + w;
+    if (r < r1) load_batch(r, bufA);
+
     float s[EPV], rcp[EPV];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-        s[j] = scale_of(amax[cv * EPV + j]);
+        s[j] = col_scale_of_word(scale_io[cv * EPV + j]);         // (amax word or, already, the final scale: same s either way)
         rcp[j] = 1.0f / s[j];
         ok = ok && scale_fast_ok(s[j]);
     }
     const bool fast = __builtin_amdgcn_ballot_w64(!ok) == 0;      // wave-uniform
-    const uint8_t* col = x + cv * (VEC ? 16 : Elem<DT>::kBytes);
-    for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
-        float f[kColUnroll][EPV];
+    __syncthreads();                                              // every wave of THIS block has read its words before wave 0 replaces them
+    if (blockIdx.x == 0 && w == 0 && live) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) scale_io[cv * EPV + j] = __builtin_bit_cast(uint32_t, s[j]);
+    }
+    auto encode_batch = [&](int64_t rb, const Raw (&raw)[kColUnroll]) {
 #pragma unroll
         for (int u = 0; u < kColUnroll; ++u) {
-            const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
-            const uint8_t* p = col + rr * ldx_bytes;
-            if constexpr (VEC) Unpack<DT, EPV>::run(*reinterpret_cast<const v4u*>(p), f[u]);
-            else f[u][0] = Elem<DT>::to_f32(*reinterpret_cast<const S*>(p));
-        }
-#pragma unroll
-        for (int u = 0; u < kColUnroll; ++u) {
-            const int64_t rr = r + 4 * u;
-            int c[EPV];
-            if (fast) {
-#pragma unroll
-                for (int j = 0; j < EPV; ++j) {
-                    const float qf = quotient_fast(f[u][j], s[j], rcp[j]);
-                    const uint32_t mb = __builtin_bit_cast(uint32_t, qf + kMagic);
-                    c[j] = (qf != qf) ? 0 : (int)(int8_t)(mb & 0xFFu);          // Q5: NaN -> 0
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < EPV; ++j) c[j] = code_of(f[u][j], s[j]);
-            }
+            const int64_t rr = rb + 4 * u;
+            float f[EPV];
+            if constexpr (VEC) Unpack<DT, EPV>::run(raw[u], f);
+            else f[0] = Elem<DT>::to_f32(raw[u]);
             if (live && rr < r1) {
                 int8_t* o = q + rr * ldq + cv * EPV;
-                if constexpr (EPV == 8) store_wt_b64(o, v2u{pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])});
-                else if constexpr (EPV == 4) store_wt_b32(o, pack4(c[0], c[1], c[2], c[3]));
-                else *o = (int8_t)c[0];
+                if (fast) {
+                    // every column of the wave passes scale_fast_ok: no NaN / Inf anywhere in these columns (they would be in the amax), |x| <= amax: the division-free
+                    // exact code of K1 (quant_device.h: one correction step for 16-bit inputs, two for fp32), packed four codes per v_perm pair
+                    uint32_t mb[EPV];
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j)
+                        mb[j] = __builtin_bit_cast(uint32_t, (kQuotientSteps<DT> == 1 ? quotient_fast1(f[j], s[j], rcp[j]) : quotient_fast(f[j], s[j], rcp[j])) + kMagic);
+                    if constexpr (EPV >= 4) {
+                        uint32_t pk[EPV / 4];
+#pragma unroll
+                        for (int g = 0; g < EPV / 4; ++g)
+                            pk[g] = __builtin_amdgcn_perm(mb[4 * g + 1], mb[4 * g], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * g + 3], mb[4 * g + 2], 0x04000c0cu);
+                        if constexpr (EPV == 8) store_wt_b64(o, v2u{pk[0], pk[1]});
+                        else store_wt_b32(o, pk[0]);
+                    } else {
+                        *o = (int8_t)(mb[0] & 0xFFu);
+                    }
+                } else {
+                    int c[EPV];
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) c[j] = code_of(f[j], s[j]);
+                    if constexpr (EPV == 8) store_wt_b64(o, v2u{pack4(c[0], c[1], c[2], c[3]), pack4(c[4], c[5], c[6], c[7])});
+                    else if constexpr (EPV == 4) store_wt_b32(o, pack4(c[0], c[1], c[2], c[3]));
+                    else *o = (int8_t)c[0];
+                }
             }
         }
+    };
+    constexpr int64_t STEP = 4 * kColUnroll;
+    while (r < r1) {
+        if (r + STEP < r1) load_batch(r + STEP, bufB);
+        encode_batch(r, bufA);
+        r += STEP;
+        if (r >= r1) break;
+        if (r + STEP < r1) load_batch(r + STEP, bufA);
+        encode_batch(r, bufB);
+        r += STEP;
     }
 }
 
-__global__ void col_finalize(float* __restrict__ scale, int64_t cols) {
+// (rows == 0 only: no encode launch — the words, all "amax 0", become scale 1.0)
+__global__ void col_finalize(uint32_t* __restrict__ scale, int64_t cols) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < cols) scale[c] = scale_of(scale[c]);
+    if (c < cols) scale[c] = __builtin_bit_cast(uint32_t, col_scale_of_word(scale[c]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,27 +504,37 @@ hipError_t quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     const bool vec_ok = (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) && aligned(q, EPV);
     const int64_t ncolv = vec_ok ? cols / EPV : cols;
-    // rows per block: aim at ~320 blocks (measured sweet spot 256-450: fewer blocks starve HBM, more pay per-block
-    // LDS reductions and atomics), in multiples of one unrolled batch
-    const int64_t strips = (ncolv + 63) / 64;
-    int64_t rpb64 = (rows * strips + 319) / 320;
-    rpb64 = (rpb64 + 4 * kColUnroll - 1) / (4 * kColUnroll) * (4 * kColUnroll);
-    const int rpb = (int)(rpb64 < 4 * kColUnroll ? 4 * kColUnroll : (rpb64 > 4096 ? 4096 : rpb64));
-    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((ncolv + 63) / 64)), block(256);
+    // rows per block: enough blocks to keep ~48 KiB per CU in flight (6 TB/s x ~2 us of latency over 256 CUs) without drowning the amax pass in per-block LDS
+    // merges and atomics: ~2 blocks per CU for the amax pass (16 KiB of raw vectors in flight per block), ~4 per CU for the encode pass (8 rows deep, no atomics);
+    // PQ_K2_BLOCKS_A / PQ_K2_BLOCKS_E (experiments) set the targets.  Multiples of one unrolled batch.
+    const int64_t strips = (ncolv + 63) / 64;                                        // encode: 64-vector strips (and the scalar fallback of both passes)
+    const int64_t strips_a = vec_ok ? (ncolv + 7) / 8 : strips;                      // amax: 8-vector strips, eight rows per wave-instruction, 16 waves per workgroup
+    auto plan = [&](int64_t target_blocks, int64_t nstrips, int batch) {
+        int64_t r = (rows * nstrips + target_blocks - 1) / target_blocks;
+        r = (r + batch - 1) / batch * batch;
+        return (int)(r < batch ? batch : (r > (1 << 20) ? (1 << 20) : r));
+    };
+    const int rpb_a = plan(opt().k2_blocks_a > 0 ? opt().k2_blocks_a : 256, strips_a, vec_ok ? 8 * kAmaxWaves * kAmaxUnroll : 4 * kColUnroll);
+    const int rpb_e = plan(opt().k2_blocks_e > 0 ? opt().k2_blocks_e : 512, strips, 4 * kColUnroll);
+    const dim3 grid_a = vec_ok ? dim3((unsigned)strips_a, (unsigned)((rows + rpb_a - 1) / rpb_a)) : dim3((unsigned)((rows + rpb_a - 1) / rpb_a), (unsigned)strips_a);
+    const dim3 grid_e((unsigned)((rows + rpb_e - 1) / rpb_e), (unsigned)strips), block(256);
+    const dim3 block_a(vec_ok ? 64 * kAmaxWaves : 256);
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const int64_t ldb = ldx * Elem<DT>::kBytes;
-    const hipError_t me = hipMemsetAsync(scale, 0, (size_t)cols * sizeof(float), st);   // amax scratch = 0 (the atomicMax identity)
-    if (me != hipSuccess) return me;                                                      // never launch on an un-zeroed scratch
+    uint32_t* words = reinterpret_cast<uint32_t*>(scale);
+    const hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(words), (int)kAmaxTag, (size_t)cols, st);   // "amax 0" (the atomicMax identity)
+    if (me != hipSuccess) return me;                                                      // never launch on an un-initialised scratch
     if (rows > 0) {
         if (vec_ok) {
-            col_amax<DT, true><<<grid, block, 0, st>>>(xb, rows, ncolv, ldb, reinterpret_cast<uint32_t*>(scale), rpb);
-            col_encode<DT, true><<<grid, block, 0, st>>>(xb, rows, ncolv, ldb, scale, q, ldq, rpb);
+            col_amax<DT, true><<<grid_a, block_a, 0, st>>>(xb, rows, ncolv, ldb, words, rpb_a);
+            col_encode<DT, true><<<grid_e, block, 0, st>>>(xb, rows, ncolv, ldb, words, q, ldq, rpb_e);
         } else {
-            col_amax<DT, false><<<grid, block, 0, st>>>(xb, rows, ncolv, ldb, reinterpret_cast<uint32_t*>(scale), rpb);
-            col_encode<DT, false><<<grid, block, 0, st>>>(xb, rows, ncolv, ldb, scale, q, ldq, rpb);
+            col_amax<DT, false><<<grid_a, block_a, 0, st>>>(xb, rows, ncolv, ldb, words, rpb_a);
+            col_encode<DT, false><<<grid_e, block, 0, st>>>(xb, rows, ncolv, ldb, words, q, ldq, rpb_e);
         }
+    } else if (cols > 0) {
+        col_finalize<<<dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st>>>(words, cols);
     }
-    col_finalize<<<dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st>>>(scale, cols);
     return hipSuccess;
 }
 
