@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-        s[j] = col_scale_of_word(scale_io[cv * EPV + j]);         // (amax word or, already, the final scale: same s either way)
+        // (amax word or, already, the final scale: same s either way.  Relaxed agent-scope atomics: the word may be replaced by another workgroup while this one reads)
+        s[j] = col_scale_of_word(__hip_atomic_load(&scale_io[cv * EPV + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         rcp[j] = 1.0f / s[j];
         ok = ok && scale_fast_ok(s[j]);
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void col_encode(const uint8_t* __restrict__ x,
     __syncthreads();                                              // every wave of THIS block has read its words before wave 0 replaces them
     if (blockIdx.x == 0 && w == 0 && live) {
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) scale_io[cv * EPV + j] = __builtin_bit_cast(uint32_t, s[j]);
+        for (int j = 0; j < EPV; ++j) __hip_atomic_store(&scale_io[cv * EPV + j], __builtin_bit_cast(uint32_t, s[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     auto encode_batch = [&](int64_t rb, const Raw (&raw)[kColUnroll]) {
 #pragma unroll
