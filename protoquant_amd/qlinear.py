@@ -160,7 +160,60 @@ def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) 
     return y.reshape(*x.shape[:-1], N)
 
 
-class qlinear(nn.Module):
+def _round_k(K: int) -> int:
+    return -(-K // 128) * 128
+
+
+class _KPadded:
+    """in_features that is not a multiple of 128 (GPT-2 XL's 1600, a 4000-wide projection): the MFMA tiles step through K in 128-byte K-tiles, and the C-ABI sends any
+    other K to the generic kernel — 4 to 25x slower than the bf16 nn.Linear it replaces (measured: 4096 x 4096 x 4000 429 us against 99).  The modules therefore keep a
+    zero-padded copy of their int8 weight, [N, round_up(K, 128)], made lazily and remade whenever `wq` changes (load_state_dict, .to()), and quantise the activation
+    into a buffer of the same width whose tail is zeroed: zeros add nothing to an integer sum, so every accumulator — and every output bit — is the unpadded problem's.
+    `wq` itself stays [N, K]: state dicts, fusion and sharding see the unpadded weight."""
+
+    def _wq_for_gemm(self):
+        K = self.in_features
+        kp = _round_k(K)
+        if kp == K or K == 0:
+            return self.wq, K
+        key = (self.wq.data_ptr(), self.wq._version, self.wq.device, tuple(self.wq.shape))
+        c = self.__dict__.get("_wq_pad")
+        if c is None or c[0] != key:
+            w = self.wq.new_zeros((self.wq.shape[0], kp))
+            w[:, :K].copy_(self.wq)
+            c = (key, w)
+            self.__dict__["_wq_pad"] = c
+        return c[1], kp
+
+    def _padded_forward(self, x, wq_pad, kp):
+        """x: float [..., K] or a per-token QTensor; the GEMM runs over kp = round_up(K, 128) with zero tails on both operands."""
+        K, N = self.in_features, self.out_features
+        if isinstance(x, QTensor):
+            src = L.row_major_2d(x.int_data.reshape(-1, K))
+            M = src.shape[0]
+            buf = torch.empty((M, kp), dtype=torch.int8, device=src.device)
+            buf[:, :K].copy_(src)
+            buf[:, K:].zero_()
+            xs, out_dtype = x.scale, x.orig_dtype
+        else:
+            L.require_gpu(x, "qlinear(x)")
+            code = L.dtype_code(x.dtype)
+            lead = 1
+            for d in x.shape[:-1]:
+                lead *= d
+            x2 = L.row_major_2d(x.reshape(lead, K))
+            M = lead
+            buf = torch.empty((M, kp), dtype=torch.int8, device=x.device)
+            buf[:, K:].zero_()
+            xs = torch.empty((M,), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                L.check(L.lib().pq_quant_rowwise(x2.data_ptr(), code, M, K, L.ld(x2), buf.data_ptr(), kp, xs.data_ptr(), L.stream_ptr(x)), "quantize")
+            out_dtype = x.dtype
+        y = qlinear_s8(buf, xs, wq_pad, self.ws, self.bias, out_dtype)
+        return y.reshape(*x.shape[:-1], N)
+
+
+class qlinear(_KPadded, nn.Module):
     """Drop-in for nn.Linear with dynamic per-token int8 activations and per-channel int8 weights."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None):
@@ -211,9 +264,12 @@ class qlinear(nn.Module):
         silu_mul_quantize() (its codes and scales go straight to the GEMM; output dtype = its orig_dtype)."""
         if x.shape[-1] != self.in_features:
             raise ValueError(f"qlinear: expected last dim {self.in_features}, got {x.shape[-1]}")
+        if isinstance(x, QTensor) and x.axis != 1:
+            raise ValueError("qlinear: a QTensor input must be quantised per token (axis=-1)")
+        wq, kp = self._wq_for_gemm()
+        if kp != self.in_features:
+            return self._padded_forward(x, wq, kp)
         if isinstance(x, QTensor):
-            if x.axis != 1:
-                raise ValueError("qlinear: a QTensor input must be quantised per token (axis=-1)")
             y = qlinear_s8(x.int_data.reshape(-1, self.in_features), x.scale, self.wq, self.ws, self.bias, x.orig_dtype)
             return y.reshape(*x.shape[:-1], self.out_features)
         return qlinear_dyn(x, self.wq, self.ws, self.bias)
@@ -222,7 +278,7 @@ class qlinear(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
 
 
-class FusedQLinear(nn.Module):
+class FusedQLinear(_KPadded, nn.Module):
     """Horizontal fusion of projections that share one input (q/k/v, gate/up): the int8 weights are concatenated
     along N, the activation is quantised ONCE and one GEMM launch fills all outputs (better tile count on 256 CUs
     than separate N=1024 GEMMs).  Exact: weight scales are per output row, so concatenation changes no value.
@@ -251,9 +307,12 @@ class FusedQLinear(nn.Module):
 
     def forward(self, x):
         """x: a float tensor [..., K] or a per-token QTensor (e.g. from rmsnorm_quantize)."""
-        xq = x if isinstance(x, QTensor) else quantize(x, axis=-1)
-        if xq.axis != 1 or xq.shape[-1] != self.in_features:
+        if x.shape[-1] != self.in_features or (isinstance(x, QTensor) and x.axis != 1):
             raise ValueError("FusedQLinear: input must be [..., in_features], quantised per token if a QTensor")
+        wq, kp = self._wq_for_gemm()
+        if kp != self.in_features:
+            return torch.split(self._padded_forward(x, wq, kp), self.splits, dim=-1)
+        xq = x if isinstance(x, QTensor) else quantize(x, axis=-1)
         y = qlinear_s8(xq.int_data.reshape(-1, self.in_features), xq.scale, self.wq, self.ws, self.bias, xq.orig_dtype)
         y = y.reshape(*x.shape[:-1], self.out_features)
         return torch.split(y, self.splits, dim=-1)

@@ -1173,3 +1173,52 @@ def test_empty_problems(pq, M, N, K):
         qw = pq.quantize(torch.randn((max(N, 1), K), device="cuda").to(torch.bfloat16))
         yd = pq.qlinear_dyn(x, qw.int_data, qw.scale, None)
         assert yd.shape == (M, max(N, 1))
+
+
+@pytest.mark.parametrize("K", [4000, 1600, 4104, 200, 72, 129])
+@pytest.mark.parametrize("M", [1, 64, 300])
+def test_modules_pad_k_to_the_mfma_k_tile(pq, K, M):
+    """in_features that is not a multiple of 128: the modules run the MFMA tiles over a zero-padded K (weights padded once, activation codes quantised into a
+    zero-tailed buffer) instead of the generic kernel — and every output bit is the unpadded problem's: against the oracle, for float and QTensor inputs, through
+    qlinear and FusedQLinear, and again after load_state_dict replaced the weights (the padded copy must follow)."""
+    N = 384
+    torch.manual_seed(K + M)
+    lin = torch.nn.Linear(K, N, bias=True, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(2, M, K, device="cuda", dtype=torch.bfloat16)
+    m = pq.qlinear.from_linear(lin)
+    assert tuple(m.wq.shape) == (N, K)                                   # the state-dict weight stays unpadded
+    wq, ws = C.quant_rowwise(bits(lin.weight), 0)
+    want, _, _, _ = Q.qlinear(bits(x.reshape(-1, K)), 0, wq, ws, bits(lin.bias))
+    y = m(x)
+    assert tuple(y.shape) == (2, M, N)
+    same(y.reshape(-1, N), want, "padded-K qlinear")
+    same(m(pq.quantize(x)).reshape(-1, N), want, "padded-K qlinear, QTensor input")
+    f = pq.FusedQLinear([m, pq.qlinear.from_linear(lin)])
+    a, b = f(x)
+    same(a.reshape(-1, N), want, "padded-K fused, first"); same(b.reshape(-1, N), want, "padded-K fused, second")
+    a, b = f(pq.quantize(x))
+    same(b.reshape(-1, N), want, "padded-K fused, QTensor input")
+    # new weights through load_state_dict: the cached padded copy is rebuilt
+    lin2 = torch.nn.Linear(K, N, bias=True, device="cuda", dtype=torch.bfloat16)
+    m.load_state_dict(pq.qlinear.from_linear(lin2).state_dict())
+    wq2, ws2 = C.quant_rowwise(bits(lin2.weight), 0)
+    want2, _, _, _ = Q.qlinear(bits(x.reshape(-1, K)), 0, wq2, ws2, bits(lin2.bias))
+    same(m(x).reshape(-1, N), want2, "padded-K qlinear after load_state_dict")
+
+
+def test_padded_k_runs_the_mfma_tiles(pq):
+    """... and it is the point of the exercise: 4096 x 4096 x 4000 through the module takes about what K = 4096 takes, not the generic kernel's 7x."""
+    def t_us(m, x):
+        for _ in range(3):
+            m(x)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            m(x)
+        b.record(); b.synchronize()
+        return a.elapsed_time(b) * 100
+    t = {}
+    for K in (4096, 4000):
+        lin = torch.nn.Linear(K, 4096, bias=False, device="cuda", dtype=torch.bfloat16)
+        t[K] = t_us(pq.qlinear.from_linear(lin), torch.randn(4096, K, device="cuda", dtype=torch.bfloat16))
+    assert t[4000] < 2.0 * t[4096], t
