@@ -213,6 +213,19 @@ class _KPadded:
         return y.reshape(*x.shape[:-1], N)
 
 
+def gemm_operands(local: "_KPadded", codes: torch.Tensor):
+    """(codes, wq) for one GEMM of a module that owns `wq`: as they are when in_features is a multiple of 128, else both zero-padded to the next one (_KPadded).
+    codes: int8 [M, in_features]."""
+    K = local.in_features
+    if K % 128 == 0 or not codes.is_cuda:      # (CPU stand-ins of the gloo host-logic tests pass through)
+        return codes, local.wq
+    wq, kp = local._wq_for_gemm()
+    buf = torch.empty((codes.shape[0], kp), dtype=torch.int8, device=codes.device)
+    buf[:, :K].copy_(codes)
+    buf[:, K:].zero_()
+    return buf, wq
+
+
 class qlinear(_KPadded, nn.Module):
     """Drop-in for nn.Linear with dynamic per-token int8 activations and per-channel int8 weights."""
 

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from .qlinear import FusedQLinear, qlinear, qlinear_s8, qlinear_s8_t
+from .qlinear import FusedQLinear, gemm_operands, qlinear, qlinear_s8, qlinear_s8_t
 from .qtensor import QTensor, quantize, silu_mul_quantize
 
 
@@ -255,10 +255,12 @@ class ColumnShardedQLinear(nn.Module):
         return quantize(x, axis=-1)                                  # replicated activation: every rank runs K1 itself
 
     def _local_rows(self, codes, scales, dtype, out=None):
-        return qlinear_s8(codes, scales, self.local.wq, self.local.ws, self.local.bias, dtype, out=out)
+        codes, wq = gemm_operands(self.local, codes)                 # (K not a multiple of 128: both zero-padded, same bits)
+        return qlinear_s8(codes, scales, wq, self.local.ws, self.local.bias, dtype, out=out)
 
     def _local_t(self, codes, scales, dtype):
-        return qlinear_s8_t(codes, scales, self.local.wq, self.local.ws, self.local.bias, dtype)
+        codes, wq = gemm_operands(self.local, codes)
+        return qlinear_s8_t(codes, scales, wq, self.local.ws, self.local.bias, dtype)
 
     def forward_t(self, x: torch.Tensor) -> torch.Tensor:
         """The transposed result yt[N, M] (M = all leading dimensions of x flattened), contiguous: the local GEMM writes transposed
@@ -398,7 +400,8 @@ class RowShardedQLinear(nn.Module):
         if xq.shape[-1] != self.local.in_features:
             raise ValueError(f"RowShardedQLinear: local input has {xq.shape[-1]} features, this rank owns {self.local.in_features}")
         b = self.local.bias.float() if self.local.bias is not None else None
-        return qlinear_s8(xq.int_data.reshape(-1, self.local.in_features), xq.scale, self.local.wq, self.local.ws, b, torch.float32)
+        codes, wq = gemm_operands(self.local, xq.int_data.reshape(-1, self.local.in_features))      # (K_r not a multiple of 128, e.g. 11008 / 8: zero-padded, same bits)
+        return qlinear_s8(codes, xq.scale, wq, self.local.ws, b, torch.float32)
 
     def forward(self, x) -> torch.Tensor:
         dtype = x.orig_dtype if isinstance(x, QTensor) else x.dtype

@@ -1222,3 +1222,41 @@ def test_padded_k_runs_the_mfma_tiles(pq):
         lin = torch.nn.Linear(K, 4096, bias=False, device="cuda", dtype=torch.bfloat16)
         t[K] = t_us(pq.qlinear.from_linear(lin), torch.randn(4096, K, device="cuda", dtype=torch.bfloat16))
     assert t[4000] < 2.0 * t[4096], t
+
+
+def test_sharded_modules_pad_k_too(pq):
+    """The sharded forms with an in_features (or a K slice per rank: 11008 / 8 = 1376) that is not a multiple of 128: rows, row chunks, transposed shards and the
+    row-sharded partial all run the padded operands (gemm_operands) and keep the bits of the plain module / the oracle partial."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        torch.manual_seed(5)
+        K, N = 1376, 640
+        lin = torch.nn.Linear(K, N, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(3, 70, K, device="cuda", dtype=torch.bfloat16)
+        wq, ws = C.quant_rowwise(bits(lin.weight), 0)
+        want, _, _, _ = Q.qlinear(bits(x.reshape(-1, K)), 0, wq, ws, bits(lin.bias))
+        y0 = pq.qlinear.from_linear(lin)(x)
+        same(y0.reshape(-1, N), want, "plain module")
+        for kw in ({}, {"overlap_chunks": 3}, {"layout": "transposed"}):
+            y1 = pq.ColumnShardedQLinear.from_linear(lin, **kw)(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y0.view(torch.int16), y1.contiguous().view(torch.int16)), kw
+        # row-sharded: rank 1 of 8 over K = 11008 owns 1376 input features
+        big = torch.nn.Linear(11008, 256, bias=False, device="cuda", dtype=torch.bfloat16)
+        xb = torch.randn(40, 11008, device="cuda", dtype=torch.bfloat16)
+        lay = pq.RowShardedQLinear.from_linear(big, world=8, rank=1)
+        assert lay.local.in_features == 1376
+        k0, k1 = 1376, 2752
+        p = lay.partial(xb[:, k0:k1].contiguous())
+        wq, ws = C.quant_rowwise(bits(big.weight), 0)                       # full-row weight scales, then the K slice (RowShardedQLinear.shard_of)
+        xq, xs = C.quant_rowwise(bits(xb[:, k0:k1].contiguous()), 0)
+        same(p, Q.epilogue(Q.gemm_s8s8s32(xq, np.ascontiguousarray(wq[:, k0:k1])), xs, ws, None, 2), "row-sharded partial")
+    finally:
+        if created:
+            dist.destroy_process_group()
