@@ -21,6 +21,9 @@ def int_mm(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
     N, K2 = wq.shape
     if K != K2 or xq.dtype != torch.int8 or wq.dtype != torch.int8:
         raise ValueError("int_mm expects int8 [M,K] and int8 [N,K]")
+    if _pad_pays(M, N, K):
+        K = _round_k(K)
+        xq, wq = _pad_k(xq, K), _pad_k(wq, K)
     acc = torch.empty((M, N), dtype=torch.int32, device=xq.device)
     with torch.cuda.device(xq.device):
         L.check(L.lib().pq_gemm_s8s8s32(xq.data_ptr(), L.ld(xq), wq.data_ptr(), L.ld(wq), acc.data_ptr(), max(N, 1),
@@ -69,6 +72,27 @@ def _check_operand(t, name: str, dev, dtype, numel=None):
         raise ValueError(f"{name} must be a contiguous vector of {numel} elements, got shape {tuple(t.shape)} stride {t.stride()}")
 
 
+def _round_k(K: int) -> int:
+    return -(-K // 128) * 128
+
+
+def _pad_k(t: torch.Tensor, kp: int) -> torch.Tensor:
+    """[rows, K] int8 -> a fresh [rows, kp] copy with a zeroed tail."""
+    K = t.shape[1]
+    buf = torch.empty((t.shape[0], kp), dtype=torch.int8, device=t.device)
+    buf[:, :K].copy_(t)
+    buf[:, K:].zero_()
+    return buf
+
+
+def _pad_pays(M: int, N: int, K: int) -> bool:
+    """The functional entry points with a K that is not a multiple of 128: the C-ABI would run its generic kernel (~300 TOPS, and ~50 when the rows are not 16-byte
+    aligned) where the MFMA tiles do 2000+.  Copying BOTH operands into zero-tailed buffers of the next multiple of 128 costs two int8 copies and four small launches
+    (~10 us + (M + N) K bytes); it pays from about 2^31 multiply-adds on (4096 x 4096 x 4000: 429 -> ~80 us).  Same bits: zeros add nothing to an integer sum.
+    (The modules keep a padded weight copy instead of making one per call: _KPadded.)"""
+    return K % 128 != 0 and K > 0 and M * N * K >= (1 << 31)
+
+
 def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
                out: torch.Tensor | None = None) -> torch.Tensor:
     """Fused int8 GEMM + dequant epilogue on pre-quantised operands (C-ABI pq_qlinear_s8)."""
@@ -84,6 +108,9 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
     dev = xq.device
     _check_operand(xq, "xq", dev, torch.int8); _check_operand(wq, "wq", dev, torch.int8)
     _check_operand(xs, "xs", dev, torch.float32, M); _check_operand(ws, "ws", dev, torch.float32, N)
+    if _pad_pays(M, N, K):
+        K = _round_k(K)
+        xq, wq = _pad_k(xq, K), _pad_k(wq, K)
     if bias is not None:
         _check_operand(bias, "bias", dev, out_dtype, N)
     if out is not None:
@@ -117,6 +144,9 @@ def qlinear_s8_t(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch
     dev = xq.device
     _check_operand(xq, "xq", dev, torch.int8); _check_operand(wq, "wq", dev, torch.int8)
     _check_operand(xs, "xs", dev, torch.float32, M); _check_operand(ws, "ws", dev, torch.float32, N)
+    if _pad_pays(M, N, K):
+        K = _round_k(K)
+        xq, wq = _pad_k(xq, K), _pad_k(wq, K)
     if bias is not None:
         _check_operand(bias, "bias", dev, out_dtype, N)
     if out is not None and (out.device != dev or out.dtype != out_dtype or out.shape != (N, M) or (M > 1 and out.stride(1) != 1)):
@@ -150,6 +180,9 @@ def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) 
     _check_operand(wq, "wq", x.device, torch.int8); _check_operand(ws, "ws", x.device, torch.float32, N)
     if bias is not None:
         _check_operand(bias, "bias", x.device, x.dtype, N)
+    if _pad_pays(lead, N, K):
+        xq = quantize(x2, axis=-1)
+        return qlinear_s8(xq.int_data, xq.scale, wq, ws, bias, x.dtype).reshape(*x.shape[:-1], N)
     y = torch.empty((lead, N), dtype=x.dtype, device=x.device)
     wbytes = L.lib().pq_qlinear_dyn_workspace_bytes(lead, N, K)
     wsp = _workspace(x.device, max(wbytes, 256))
@@ -158,10 +191,6 @@ def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) 
                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), max(N, 1),
                                        lead, N, K, wsp.data_ptr(), wsp.numel(), L.stream_ptr(x)), "qlinear_dyn")
     return y.reshape(*x.shape[:-1], N)
-
-
-def _round_k(K: int) -> int:
-    return -(-K // 128) * 128
 
 
 class _KPadded:

@@ -1260,3 +1260,28 @@ def test_sharded_modules_pad_k_too(pq):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K", [4000, 1608, 1001])
+def test_functional_entry_points_pad_k_when_it_pays(pq, K):
+    """int_mm / qlinear_s8 / qlinear_s8_t / qlinear_dyn with a K that is not a multiple of 128 on a problem large enough (>= 2^31 multiply-adds): both operands are
+    copied into zero-tailed buffers and the MFMA tiles run — every bit as from the unpadded operands (torch._int_mm on this GPU; QSPEC E1-E4 in stock torch ops)."""
+    M, N = 1536, 2048
+    g = torch.Generator(device="cuda"); g.manual_seed(K)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    xs = torch.rand(M, device="cuda", generator=g) * 0.02 + 1e-3
+    ws = torch.rand(N, device="cuda", generator=g) * 0.002 + 1e-4
+    bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    kp = -(-K // 8) * 8                                            # torch._int_mm wants K % 8 == 0: its own zero padding
+    ap = torch.zeros((M, kp), dtype=torch.int8, device="cuda"); ap[:, :K] = a
+    bp = torch.zeros((N, kp), dtype=torch.int8, device="cuda"); bp[:, :K] = b
+    acc = torch._int_mm(ap, bp.t())
+    assert torch.equal(pq.int_mm(a, b), acc)
+    ref = ((acc.float() * xs[:, None]) * ws[None, :] + bias.float()[None, :]).to(torch.bfloat16)
+    assert torch.equal(pq.qlinear_s8(a, xs, b, ws, bias, torch.bfloat16).view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(pq.qlinear_s8_t(a, xs, b, ws, bias, torch.bfloat16).t().contiguous().view(torch.int16), ref.view(torch.int16))
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    q = pq.quantize(x)
+    y = pq.qlinear_dyn(x, b, ws, bias)
+    assert torch.equal(y.view(torch.int16), pq.qlinear_s8(q.int_data, q.scale, b, ws, bias, torch.bfloat16).view(torch.int16))
