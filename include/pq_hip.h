@@ -50,7 +50,8 @@ const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
  * ring64x128 | ring64x64 | skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
  * split-K, S = S slices), PQ_FSK_SYMMETRIC and PQ_FSK_FENCED (see pq_qlinear_s8), PQ_NO_MIDM (no 64-row ring tiles), PQ_RING_ROT (0 = no K rotation), PQ_FAKE_CUS (plan as if the device had n CUs),
- * PQ_SKINNY_RB ("" = off / auto).  The environment variables of the same names are read ONCE, at the first call into the
+ * PQ_SKINNY_RB ("" = off / auto), PQ_EPI_ANY_ALIGN (0 = the staged epilogue only for 16-byte aligned output rows; default: any element-aligned row),
+ * PQ_K2_BLOCKS_A / PQ_K2_BLOCKS_E (workgroup-count targets of K2's two passes).  The environment variables of the same names are read ONCE, at the first call into the
  * library; this call changes a switch afterwards.
  * Threading: the switches live in an immutable snapshot; pq_set_option publishes a modified copy with one atomic pointer
  * swap, and every other entry point pins the snapshot that is live when it is ENTERED and plans and launches under that
@@ -65,8 +66,8 @@ int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t col
                          int8_t* q, int64_t ld_q, float* scale, void* stream);
 
 /* K2 — per-channel quantisation of a row-major matrix along its strided axis (amax over rows):
- * replaces quantize(W) for a [K, N]-stored weight.  scale[cols] f32.  Three stream-ordered launches
- * (amax, encode, finalise); `scale` doubles as the amax scratch — no workspace.   QSPEC Q1-Q6. */
+ * replaces quantize(W) for a [K, N]-stored weight.  scale[cols] f32.  Three stream-ordered graph nodes
+ * (a 32-bit memset, the amax pass, the encode pass); `scale` doubles as the amax scratch — no workspace.   QSPEC Q1-Q6. */
 int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x,
                          int8_t* q, int64_t ld_q, float* scale, void* stream);
 

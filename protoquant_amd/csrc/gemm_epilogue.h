@@ -14,7 +14,14 @@ struct EpiArgs {
     void* y;                // [M, ldy]
     int64_t ldy;
     int32_t flags;          // EPI_* bits; 0 = QSPEC as written: (f32(acc) * a_scale[row]) * b_scale[col] (+ bias[col])
+    int32_t y_any_align = 0;   // 1: the staged epilogue may store its 16-byte pieces at element-aligned addresses (odd leading dimensions, e.g. a 50257-wide vocabulary)
 };
+// rows of y fit the staged epilogue's 16-byte write-through stores: 16-byte aligned rows, or (y_any_align) any element-aligned address — gfx950 compute queues run
+// with unaligned access enabled, and the stores are inline asm: no compiler alignment assumption is involved
+__device__ __forceinline__ bool epi_rows_storable(const EpiArgs& e, const void* y, int ob) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(y);
+    return e.y_any_align ? (a & (uintptr_t)(ob - 1)) == 0 : ((a & 15) == 0 && ((e.ldy * ob) & 15) == 0);
+}
 // The transposed product y^T = Wq . xq^T (pq_qlinear_s8_t: the GEMM's rows are output channels n, its columns tokens m) must
 // still round as QSPEC E2-E3 say — the TOKEN scale first — so the column scale is applied first and the bias runs along rows.
 constexpr int32_t EPI_COL_FIRST = 1, EPI_BIAS_ROWS = 2;

@@ -570,7 +570,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
         constexpr int ROW0 = HALFQ < 0 ? 0 : HALFQ * QW;
         // staged path: whole block in range, 16-byte aligned rows
         const bool staged = !direct_epi && scales_in_lds && (wm0 + WM <= M) && (wn0 + WN <= N) &&
-                            ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+                            epi_rows_storable(epi, y, OB) &&
                             (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
         if (staged) {
             // Staging region: this wave's eighth of the ring slot AFTER the last K-tile's.  Nobody reads that slot any more
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_p3_persist(const int8_t* __res
         const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
         const int wm0 = cm0 + wq * WM, wn0 = cn0 + wp * WN;
         const int scale_off = inc3(sp, NT % 3) * PB;                                    // K-tile NT-3's weight slot
-        const bool staged = scales_ok && (wm0 + WM <= M) && (wn0 + WN <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+        const bool staged = scales_ok && (wm0 + WM <= M) && (wn0 + WN <= N) && epi_rows_storable(epi, y, OB) &&
                             (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
         constexpr int NSTORE = (OB == 2) ? 16 : 32;          // global stores per wave of the staged epilogue
         if (staged) {
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
     const int wm0 = m0 + wq * 64, wn0 = n0 + wp * 64;
-    const bool staged = (wm0 + 64 <= M) && (wn0 + 64 <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+    const bool staged = (wm0 + 64 <= M) && (wn0 + 64 <= N) && epi_rows_storable(epi, y, OB) &&
                         (OUT == OUT_I32 || (reinterpret_cast<uintptr_t>(epi.b_scale) & 15) == 0) &&
                         (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
     if (staged) {

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     const bool has_bias = (OUT != OUT_I32) && epi.bias != nullptr;
     const int dcol = lane & 15, drow4 = (lane >> 4) * 4;
     const int wm0 = m0 + wq * (TM / 2), wn0 = n0 + wp * (TN / 2);
-    const bool staged = (wm0 + TM / 2 <= M) && (wn0 + TN / 2 <= N) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (((epi.ldy * OB) & 15) == 0) &&
+    const bool staged = (wm0 + TM / 2 <= M) && (wn0 + TN / 2 <= N) && epi_rows_storable(epi, y, OB) &&
                         (OUT == OUT_I32 || (reinterpret_cast<uintptr_t>(epi.b_scale) & 15) == 0) &&
                         (!has_bias || (reinterpret_cast<uintptr_t>(epi.bias) & (4 * OB - 1)) == 0);
     if (staged) {

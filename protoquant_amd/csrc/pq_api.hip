@@ -77,7 +77,7 @@ thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
     const int iv = set ? atoi(value) : 0;
@@ -100,6 +100,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_RING_LC")) o.ring_lc = !(set && *value == '0');
     else if (!strcmp(name, "PQ_RING_ROT")) o.ring_rot = !set ? 1 : (iv < 0 ? 0 : iv);
     else if (!strcmp(name, "PQ_K1_LDS")) o.k1_lds = iv < 0 ? 0 : (iv > 65536 ? 65536 : iv);
+    else if (!strcmp(name, "PQ_EPI_ANY_ALIGN")) o.epi_any_align = !(set && *value == '0');
     else if (!strcmp(name, "PQ_K2_BLOCKS_A")) o.k2_blocks_a = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_K2_BLOCKS_E")) o.k2_blocks_e = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
@@ -446,9 +447,11 @@ size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // the GEMM + epilogue of one (M x N x K, A rows x B rows) problem whose EpiArgs are already in the kernel's orientation
-static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi,
+static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb, const pq::EpiArgs& epi_in,
                             int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
     Range range_("pq:qlinear_s8 (K3+K4)");
+    pq::EpiArgs epi = epi_in;
+    epi.y_any_align = options().epi_any_align ? 1 : 0;
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.

@@ -1285,3 +1285,31 @@ def test_functional_entry_points_pad_k_when_it_pays(pq, K):
     q = pq.quantize(x)
     y = pq.qlinear_dyn(x, b, ws, bias)
     assert torch.equal(y.view(torch.int16), pq.qlinear_s8(q.int_data, q.scale, b, ws, bias, torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("setting", ["", "0"])
+@pytest.mark.parametrize("M,N,K", [(512, 4001, 512), (300, 777, 640), (4096, 1025, 1024), (128, 50257, 256)])
+def test_odd_leading_dimensions_of_y(pq, pq_opt, setting, M, N, K):
+    """Output rows that are not 16-byte aligned (odd N: a 50257-wide vocabulary): by default the staged epilogue stores its 16-byte pieces at element-aligned addresses
+    (gfx950 compute queues run with unaligned access enabled; -26 % at 2048 x 50257 x 4096); PQ_EPI_ANY_ALIGN=0 keeps the round-3 behaviour (guarded direct stores).
+    Same bits either way, for every output type."""
+    pq_opt("PQ_EPI_ANY_ALIGN", setting)
+    g = torch.Generator(device="cuda"); g.manual_seed(N)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    b = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    xs = torch.rand(M, device="cuda", generator=g) * 0.02 + 1e-3
+    ws = torch.rand(N, device="cuda", generator=g) * 0.002 + 1e-4
+    acc = pq.int_mm(a, b)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        bias = torch.randn(N, device="cuda", generator=g).to(dtype)
+        ref = ((acc.float() * xs[:, None]) * ws[None, :] + bias.float()[None, :]).to(dtype)
+        y = pq.qlinear_s8(a, xs, b, ws, bias, dtype)
+        view = torch.int16 if dtype != torch.float32 else torch.int32
+        assert torch.equal(y.view(view), ref.view(view)), dtype
+        # a padded, offset output buffer: nothing outside [M, N] is touched
+        big = torch.full((M + 2, N + 5), 7.0, dtype=dtype, device="cuda")
+        out = big[1:M + 1, 3:N + 3]
+        pq.qlinear_s8(a, xs, b, ws, bias, dtype, out=out)
+        assert torch.equal(out.contiguous().view(view), ref.view(view))
+        big[1:M + 1, 3:N + 3] = 7.0
+        assert bool((big == 7.0).all()), "stores outside the output"
