@@ -287,6 +287,20 @@ class qlinear(_KPadded, nn.Module):
         return m
 
     @classmethod
+    def from_kn_weight(cls, weight_kn: torch.Tensor, bias=None) -> "qlinear":
+        """A weight STORED [in_features, out_features] (y = x @ W + b: Hugging Face GPT-2's Conv1D): per-output-channel quantisation along the strided axis of the
+        matrix as it lies in memory (kernel K2 — no transposed bf16 copy is made), then ONE transpose of the int8 codes into the [N, K] layout the GEMM streams.
+        Codes and scales are those of from_linear on the transposed weight, bit for bit (the same max and the same quotients, reduced along the other axis)."""
+        w = weight_kn.detach()
+        L.require_gpu(w, "qlinear.from_kn_weight(weight)")
+        if w.dim() != 2:
+            raise ValueError("from_kn_weight expects a 2-D [in_features, out_features] weight")
+        qw = quantize(w, axis=0)                                    # int_data [K, N], scale [N]
+        K, N = w.shape
+        sub = QTensor(qw.int_data.t().contiguous(), qw.scale, 1, w.dtype, torch.Size((N, K)))
+        return cls.from_qtensor(sub, bias.detach().clone() if bias is not None else None)
+
+    @classmethod
     def from_qtensor(cls, qw: QTensor, bias=None) -> "qlinear":
         if qw.axis != 1 or qw.int_data.dim() != 2:
             raise ValueError("weight QTensor must be [N,K] quantised per output channel (axis=-1)")
@@ -396,8 +410,16 @@ def _as_gated_mlp(mod: nn.Module):
     return GatedMLP.from_linears(g, u, d)
 
 
+def _is_conv1d(mod: nn.Module) -> bool:
+    """transformers.pytorch_utils.Conv1D (GPT-2 family): a linear layer whose weight is stored [in_features, out_features] (recognised by shape, not by import)."""
+    w = getattr(mod, "weight", None)
+    return (type(mod).__name__ == "Conv1D" and isinstance(getattr(mod, "nf", None), int) and isinstance(w, torch.Tensor) and w.dim() == 2
+            and w.shape[1] == mod.nf and not list(mod.children()))
+
+
 def swap_linears(model: nn.Module, predicate=None, fuse_gated_mlp: bool = False) -> nn.Module:
-    """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place.
+    """Replace every nn.Linear (for which predicate(name, module) is true) by qlinear, in place; Hugging Face Conv1D layers (GPT-2: weight stored [K, N]) likewise,
+    through qlinear.from_kn_weight (per-channel quantisation along the strided axis, kernel K2).
     fuse_gated_mlp=True additionally replaces whole gated-MLP blocks (gate_proj / up_proj / down_proj + SiLU, the
     Llama-family MLP) by GatedMLP: one fused gate+up GEMM, silu*mul fused into the quantisation, the down GEMM."""
     for name, child in list(model.named_children()):
@@ -408,6 +430,8 @@ def swap_linears(model: nn.Module, predicate=None, fuse_gated_mlp: bool = False)
                 continue
         if isinstance(child, nn.Linear) and (predicate is None or predicate(name, child)):
             setattr(model, name, qlinear.from_linear(child))
+        elif _is_conv1d(child) and (predicate is None or predicate(name, child)):
+            setattr(model, name, qlinear.from_kn_weight(child.weight, child.bias))      # Hugging Face GPT-2's Conv1D: y = x @ W[K, N] + b
         else:
             swap_linears(child, predicate, fuse_gated_mlp)
     return model

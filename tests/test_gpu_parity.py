@@ -1313,3 +1313,41 @@ def test_odd_leading_dimensions_of_y(pq, pq_opt, setting, M, N, K):
         assert torch.equal(out.contiguous().view(view), ref.view(view))
         big[1:M + 1, 3:N + 3] = 7.0
         assert bool((big == 7.0).all()), "stores outside the output"
+
+
+def test_kn_stored_weights_and_a_transformers_gpt2(pq):
+    """Weights stored [in_features, out_features] (Hugging Face GPT-2's Conv1D): qlinear.from_kn_weight quantises along the strided axis (K2) and is, bit for bit,
+    from_linear on the transposed weight; swap_linears turns every Conv1D of a transformers GPT2LMHeadModel — and its 50257-wide lm_head (odd N: the unaligned staged
+    epilogue) — into qlinear, and the swapped model's logits equal those of the same model with its Conv1D layers rewritten as nn.Linear and swapped."""
+    torch.manual_seed(11)
+    w_kn = torch.randn(640, 392, device="cuda").to(torch.bfloat16)
+    b = torch.randn(392, device="cuda").to(torch.bfloat16)
+    m1 = pq.qlinear.from_kn_weight(w_kn, b)
+    lin = torch.nn.Linear(640, 392, bias=True, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(w_kn.t()); lin.bias.copy_(b)
+    m2 = pq.qlinear.from_linear(lin)
+    assert torch.equal(m1.wq, m2.wq) and torch.equal(m1.ws.view(torch.int32), m2.ws.view(torch.int32))
+    x = torch.randn(3, 17, 640, device="cuda").to(torch.bfloat16)
+    assert torch.equal(m1(x).view(torch.int16), m2(x).view(torch.int16))
+
+    tr = pytest.importorskip("transformers")
+    cfg = tr.GPT2Config(n_embd=256, n_layer=2, n_head=4, n_positions=64, vocab_size=50257)
+    model = tr.GPT2LMHeadModel(cfg).to(torch.bfloat16).cuda().eval()
+    import copy
+    twin = copy.deepcopy(model)
+    n_conv = sum(1 for mod in model.modules() if type(mod).__name__ == "Conv1D")
+    assert n_conv == 8                                              # c_attn, c_proj, c_fc, c_proj per layer
+    for parent in list(twin.modules()):                             # the twin: every Conv1D rewritten as the nn.Linear it is
+        for name, child in list(parent.named_children()):
+            if type(child).__name__ == "Conv1D":
+                l = torch.nn.Linear(child.weight.shape[0], child.nf, bias=True, device="cuda", dtype=torch.bfloat16)
+                with torch.no_grad():
+                    l.weight.copy_(child.weight.t()); l.bias.copy_(child.bias)
+                setattr(parent, name, l)
+    pq.swap_linears(model); pq.swap_linears(twin)
+    assert sum(1 for mod in model.modules() if isinstance(mod, pq.qlinear)) == n_conv + 1      # + lm_head
+    ids = torch.randint(0, 50257, (2, 48), device="cuda")
+    with torch.no_grad():
+        a = model(ids).logits; bb = twin(ids).logits
+    assert a.shape == (2, 48, 50257) and torch.equal(a.view(torch.int16), bb.view(torch.int16))
