@@ -1351,3 +1351,25 @@ def test_kn_stored_weights_and_a_transformers_gpt2(pq):
     with torch.no_grad():
         a = model(ids).logits; bb = twin(ids).logits
     assert a.shape == (2, 48, 50257) and torch.equal(a.view(torch.int16), bb.view(torch.int16))
+
+
+def test_padded_k_module_is_graph_capturable(pq):
+    """The padded-K forward (fresh code buffer, zeroed tail, K1 with a wider ld_q, the GEMM over the padded weight copy) under hipGraph capture and replay."""
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(1000, 512, bias=True, device="cuda", dtype=torch.bfloat16)
+    m = pq.qlinear.from_linear(lin)
+    x = torch.randn(64, 1000, device="cuda", dtype=torch.bfloat16)
+    want = m(x).clone()                                             # warm-up: builds the padded weight copy outside the capture
+    out = torch.empty_like(want)
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out.copy_(m(x))
+        for _ in range(3):
+            out.zero_(); g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    x.copy_(torch.randn(64, 1000, device="cuda").to(torch.bfloat16))
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), m(x).view(torch.int16))
