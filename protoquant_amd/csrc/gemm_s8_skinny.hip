@@ -206,24 +206,43 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
     }
 }
 
-// KS: enough waves for ~8 per CU overall, at least two k-step batches per wave, at most 16 waves per workgroup
-static int skinny_ks(int64_t blocks, int64_t K, int mt, int rb) {
-    const int64_t steps = K / 64;
+// (RB, KS) of a launch: weight blocks per wave and the K split (waves per workgroup).  Round 4 swept both over 19 decode-like shapes, weights from HBM
+// (profiles/r04_skinny_sweep.txt); the rules below are that table's arg-min, within 3 % on every shape (the round-3 rule — two blocks per wave from N = 6144 on,
+// ~4096 waves per launch — was 5 - 21 % off on eleven of them):
+//   * one token: one block per wave, at least four waves per workgroup (the waves of a workgroup walk the SAME 16 weight rows at different K offsets: with one
+//     wave per workgroup thousands of rows are open at once, 64 bytes at a time — lm_head 115 us against 93), ~4096 waves per launch;
+//   * 2 .. 32 tokens (the activation fragments are real traffic): narrow matrices (N < 6144) one block per wave and ~2048 waves; 6144 <= N < 16384 two blocks per
+//     wave (every activation fragment reused twice) and only ~768 waves; from N = 16384 on one block per wave again, split in 4 (up to 8 tokens) or 2;
+//   * 33 .. 64 tokens (three or four token tiles; only against narrow matrices): one block per wave, ~4096 waves — unchanged.
+// Always at least one k-step batch per wave, at most 16 waves per workgroup.  PQ_SKINNY_RB / PQ_SKINNY_KS force either.
+static void skinny_plan(int64_t M, int64_t N, int64_t K, int* rb_out, int* ks_out) {
+    const int mt = (int)((M + 15) / 16);
+    int rb = 1, min_ks = 1;
+    int64_t target = 4096;
+    if (mt <= 2) {
+        if (M == 1) min_ks = 4;
+        else if (N < 6144) target = 2048, min_ks = 2;
+        else if (N < 16384) rb = 2, target = 768, min_ks = 2;
+        else target = 1, min_ks = M <= 8 ? 4 : 2;
+    }
+    if (const int f = opt().skinny_rb; f && mt <= 2) rb = f;
+    const int64_t blocks = (N + 16 * rb - 1) / (16 * rb), steps = K / 64;
     int ks = 1;
-    while (ks < 16 && blocks * ks < 4096 && steps / (ks * 2) >= sk_batch(mt, rb)) ks <<= 1;
-    return ks;
+    while (ks < 16 && (blocks * ks < target || ks < min_ks) && steps / (ks * 2) >= sk_batch(mt, rb)) ks <<= 1;
+    if (const int f = opt().skinny_ks; f > 0) {            // PQ_SKINNY_KS (experiments): a forced power of two, clamped to what the K-steps allow
+        ks = 1;
+        while (ks < f && ks < 16 && steps / (ks * 2) >= 1) ks <<= 1;
+    }
+    *rb_out = rb; *ks_out = ks;
 }
-// two weight blocks per wave once that still leaves >= 192 workgroups (measured: N = 6144 10.2 -> 8.3 us at 16 tokens, lm_head
-// 148 -> 124 us; N = 4096 would drop to 128 workgroups: 6.3 -> 8.1 us)
-static bool skinny_rb2(int64_t N) { const int rb = opt().skinny_rb; return rb ? rb == 2 : N >= 6144; }     // PQ_SKINNY_RB: 0 auto, 1 / 2 forced
 
 template <int OUT>
 void launch_gemm_skinny(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
                         int64_t K, hipStream_t st) {
     const int mt = (int)((M + 15) / 16);
-    const int rb = (mt <= 2 && skinny_rb2(N)) ? 2 : 1;     // (3-4 token tiles x 2 blocks would not fit the register budget)
+    int rb = 1, ks = 1;                                    // (3-4 token tiles x 2 blocks would not fit the register budget: skinny_plan keeps rb = 1 there)
+    skinny_plan(M, N, K, &rb, &ks);
     const int64_t blocks = (N + 16 * rb - 1) / (16 * rb);
-    const int ks = skinny_ks(blocks, K, mt, rb);
     const dim3 grid((unsigned)blocks), block((unsigned)(ks * 64));
     const bool stage = opt().skinny_stage && M > 1;       // (one token: its 16 "rows" are one clamped row — the direct loads are already cheap)
     const size_t lds_red = ks > 1 ? (size_t)ks * mt * rb * 64 * sizeof(v4i) : 0;

@@ -77,7 +77,7 @@ thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
 const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
-                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE"};
+                                    "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE", "PQ_SKINNY_KS"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
     const int iv = set ? atoi(value) : 0;
@@ -106,6 +106,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_K1_ST16")) o.k1_st16 = set && *value == '1';
     else if (!strcmp(name, "PQ_K1_RPW")) o.k1_rpw = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
     else if (!strcmp(name, "PQ_SKINNY_STAGE")) o.skinny_stage = !(set && *value == '0');
+    else if (!strcmp(name, "PQ_SKINNY_KS")) o.skinny_ks = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_SKINNY_RB")) o.skinny_rb = set && *value == '2' ? 2 : (set && *value == '1' ? 1 : 0);
     else return false;
     return true;

@@ -36,6 +36,7 @@ struct Options {
     int skinny_rb = 0;               // 0 auto, 1 / 2 forced
     int k1_rpw = 0;                  // 0 auto, 1 / 2 forced
     bool k1_st16 = false;            // 16-byte code stores in K1: A/B in profiles/r03_k1_st16.txt
+    int skinny_ks = 0;               // PQ_SKINNY_KS (experiments): forced K-split of the weight-streaming kernel (waves per workgroup)
     bool epi_any_align = true;       // PQ_EPI_ANY_ALIGN=0: the staged epilogue only for 16-byte aligned rows of y (round 4 default: any element-aligned row — odd leading dimensions, a 50257-wide vocabulary: 498 -> 370 us)
     int k2_blocks_a = 0, k2_blocks_e = 0;   // PQ_K2_BLOCKS_A / _E (experiments): target workgroup counts of K2's amax / encode passes (0 = default)
     int k1_lds = 0;                  // experiment: bytes of unused dynamic LDS per block = a cap on resident blocks per CU
