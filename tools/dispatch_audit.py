@@ -1,6 +1,6 @@
 """Dev tool (GPU box): audit of the dispatcher.  Over a grid of (M, N, K) it times pq_qlinear_s8 as dispatched ("auto") and with every tile variant forced, all from hipGraph
 replays over a rotation of weight matrices (HBM-fed, what a layer inside a model sees), interleaved round by round, and lists the shapes where the dispatch is more than
-5 % slower than the best forced variant.  usage: python tools/dispatch_audit.py [--quick]"""
+5 % slower than the best forced variant.  usage: python tools/dispatch_audit.py [--quick] [--small]"""
 import ctypes, os, sys
 import torch
 i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
@@ -14,6 +14,8 @@ L.pq_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
 VARS = ["", "sp256_16", "sp128_16", "ring128", "ring64x128", "ring64x64", "skinny"]
 quick = "--quick" in sys.argv
 Ms = [48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192]
+if "--small" in sys.argv:            # the decode-like end: the weight-streaming kernel against the 64-row ring tiles
+    Ms = [1, 8, 16, 17, 24, 32, 33, 40, 48, 64]
 Ns = [512, 1024, 2048, 4096, 6144, 8192, 14336, 28672]
 Ks = [1024, 4096, 8192] if not quick else [4096]
 dev = torch.device("cuda:0")
