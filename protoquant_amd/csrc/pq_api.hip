@@ -177,7 +177,9 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // grid cannot fill the chip (N <= 8192); three and four token tiles (33 .. 64 tokens) only against narrow matrices (N < 6144) — from 6144 output channels on, the
     // 64-row ring tiles of round 4 have enough tiles and win (HBM-fed: 64 x 6144 x 4096 17.9 -> 13.2 us, 64 x 28672 x 4096 46.7 -> 31.6; but 64 x 4096 x 4096 10.4 against
     // 12.7 and 64 x 4096 x 14336 26.3 against 36.3 stay here: profiles/r04_midm_decode.txt).  PQ_NO_MIDM=1: the round-3 split (<= 64 tokens, N <= 8192).
-    if (M <= 16 || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144))) return V_SKINNY;
+    // (round 4 audit, tools/dispatch_audit.py --small, two boxes: 17 .. 24 tokens against the widest matrices with K <= 4096 stay with the streaming kernel — 17 x 28672 x 4096
+    // 32.2 us against 34.8 for the 64 x 128 ring tile)
+    if (M <= 16 || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144)) || (!options().no_midm && M <= 24 && N >= 16384 && K <= 4096)) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): audit of the dispatcher.  Over a grid of (M, N, K) it times pq_qlinear_s8 as dispatched ("auto") and with every tile variant forced, all from hipGraph
 replays over a rotation of weight matrices (HBM-fed, what a layer inside a model sees), interleaved round by round, and lists the shapes where the dispatch is more than
-5 % slower than the best forced variant.  usage: python tools/dispatch_audit.py [--quick] [--small]"""
+5 % slower than the best forced variant.  usage: python tools/dispatch_audit.py [--quick] [--small] [--all-times]"""
 import ctypes, os, sys
 import torch
 i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
@@ -64,7 +64,8 @@ for K in Ks:
             med = {v: sorted(t)[len(t) // 2] for v, t in ts.items()}
             best = min((t, v) for v, t in med.items() if v)
             flag = med[""] > 1.05 * best[0]
-            line = f"{M:5d}x{N:5d}x{K:5d} auto {med['']:8.2f} us [{graphs[''][2]:28s}] best forced {best[0]:8.2f} [{best[1]}]" + (f"   <-- {100 * (med[''] / best[0] - 1):.0f} % slower" if flag else "")
+            extra = ("  | " + " ".join(f"{v}:{t:.1f}" for v, t in med.items() if v)) if "--all-times" in sys.argv else ""
+            line = f"{M:5d}x{N:5d}x{K:5d} auto {med['']:8.2f} us [{graphs[''][2]:28s}] best forced {best[0]:8.2f} [{best[1]}]{extra}" + (f"   <-- {100 * (med[''] / best[0] - 1):.0f} % slower" if flag else "")
             print(line, flush=True)
             if flag:
                 bad.append(line)
