@@ -179,7 +179,10 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // 12.7 and 64 x 4096 x 14336 26.3 against 36.3 stay here: profiles/r04_midm_decode.txt).  PQ_NO_MIDM=1: the round-3 split (<= 64 tokens, N <= 8192).
     // (round 4 audit, tools/dispatch_audit.py --small, two boxes: 17 .. 24 tokens against the widest matrices with K <= 4096 stay with the streaming kernel — 17 x 28672 x 4096
     // 32.2 us against 34.8 for the 64 x 128 ring tile)
-    if (M <= 16 || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144)) || (!options().no_midm && M <= 24 && N >= 16384 && K <= 4096)) return V_SKINNY;
+    // ... and 9 .. 16 tokens against wide matrices with a LONG K (K >= 8192, N >= 14336: Llama-70B's gate / up at batch 16) go to the ring tiles: 16 x 28672 x 8192 55.5 - 57 us
+    // against 59.7 streaming, 16 x 14336 x 8192 28.4 against 30.0 (8 tokens: the streaming kernel still wins at N = 28672, 49 against 55)
+    const bool long_k_ring = !options().no_midm && M > 8 && M <= 16 && N >= 14336 && K >= 8192;
+    if ((M <= 16 && !long_k_ring) || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144)) || (!options().no_midm && M <= 24 && N >= 16384 && K <= 4096)) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
