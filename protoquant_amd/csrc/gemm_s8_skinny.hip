@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
 // ~4096 waves per launch — was 5 - 21 % off on eleven of them):
 //   * one token: one block per wave, at least four waves per workgroup (the waves of a workgroup walk the SAME 16 weight rows at different K offsets: with one
 //     wave per workgroup thousands of rows are open at once, 64 bytes at a time — lm_head 115 us against 93), ~4096 waves per launch;
-//   * 2 .. 32 tokens (the activation fragments are real traffic): narrow matrices (N < 6144) one block per wave and ~2048 waves; 6144 <= N < 16384 two blocks per
+//   * 2 .. 32 tokens (the activation fragments are real traffic): narrow matrices (N <= 4096) one block per wave and ~2048 waves; 4096 < N < 16384 two blocks per
 //     wave (every activation fragment reused twice) and only ~768 waves; from N = 16384 on one block per wave again, split in 4 (up to 8 tokens) or 2;
 //   * 33 .. 64 tokens (three or four token tiles; only against narrow matrices): one block per wave, ~4096 waves — unchanged.
 // Always at least one k-step batch per wave, at most 16 waves per workgroup.  PQ_SKINNY_RB / PQ_SKINNY_KS force either.
@@ -221,8 +221,8 @@ static void skinny_plan(int64_t M, int64_t N, int64_t K, int* rb_out, int* ks_ou
     int64_t target = 4096;
     if (mt <= 2) {
         if (M == 1) min_ks = 4;
-        else if (N < 6144) target = 2048, min_ks = 2;
-        else if (N < 16384) rb = 2, target = 768, min_ks = 2;
+        else if (N <= 4096) target = 2048, min_ks = 2;
+        else if (N < 16384) rb = 2, target = 768, min_ks = 2;     // (from N = 4097 on: 16-row blocks of a 5120-wide matrix are 320 workgroups, a round and a quarter of the chip)
         else target = 1, min_ks = M <= 8 ? 4 : 2;
     }
     if (const int f = opt().skinny_rb; f && mt <= 2) rb = f;

@@ -174,7 +174,7 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     if (f == V_SKINNY) return M <= 64 ? V_SKINNY : V_RING128;      // the skinny kernel holds at most 4 token tiles
     if (f != V_AUTO) return f;
     // decode-like: stream the weights straight into MFMA fragments (HBM-bound).  One 16-token tile: always (4096x4096 6 us vs 18 us tiled); two token tiles while the tiled
-    // grid cannot fill the chip (N <= 8192); three and four token tiles (33 .. 64 tokens) only against narrow matrices (N < 6144) — from 6144 output channels on, the
+    // grid cannot fill the chip (N <= 8192); three and four token tiles (33 .. 64 tokens) only against narrow matrices (N <= 4096: one round of 16-row blocks; a 5120-wide matrix is a round and a quarter — 64 x 5120 x 11008 43.7 us streaming, 30.7 on 64 x 64 ring tiles) — beyond, the
     // 64-row ring tiles of round 4 have enough tiles and win (HBM-fed: 64 x 6144 x 4096 17.9 -> 13.2 us, 64 x 28672 x 4096 46.7 -> 31.6; but 64 x 4096 x 4096 10.4 against
     // 12.7 and 64 x 4096 x 14336 26.3 against 36.3 stay here: profiles/r04_midm_decode.txt).  PQ_NO_MIDM=1: the round-3 split (<= 64 tokens, N <= 8192).
     // (round 4 audit, tools/dispatch_audit.py --small, two boxes: 17 .. 24 tokens against the widest matrices with K <= 4096 stay with the streaming kernel — 17 x 28672 x 4096
@@ -182,7 +182,7 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // ... and 9 .. 16 tokens against wide matrices with a LONG K (K >= 8192, N >= 14336: Llama-70B's gate / up at batch 16) go to the ring tiles: 16 x 28672 x 8192 55.5 - 57 us
     // against 59.7 streaming, 16 x 14336 x 8192 28.4 against 30.0 (8 tokens: the streaming kernel still wins at N = 28672, 49 against 55)
     const bool long_k_ring = !options().no_midm && M > 8 && M <= 16 && N >= 14336 && K >= 8192;
-    if ((M <= 16 && !long_k_ring) || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 6144)) || (!options().no_midm && M <= 24 && N >= 16384 && K <= 4096)) return V_SKINNY;
+    if ((M <= 16 && !long_k_ring) || (M <= 32 && N <= 8192) || (M <= 64 && N < (options().no_midm ? 8193 : 4097)) || (!options().no_midm && M <= 24 && N >= 16384 && K <= 4096)) return V_SKINNY;
     if (M * N < 128 * 128) return V_GENERIC;   // a 256^2 tile would be mostly padding
     // 256x256 tiles unless they fill well under one round of the 256 CUs: then 128(m) x 256(n) tiles double the
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.

@@ -1116,7 +1116,7 @@ def test_errors_are_loud(pq):
     assert st == 1 and b"pq_quant_rowwise" in L.pq_last_error()
 
 
-@pytest.mark.parametrize("M,N,K,want", [(48, 6144, 4096, "ring64x64"), (64, 28672, 4096, "ring64x128"), (24, 28672, 4096, "skinny"), (16, 28672, 8192, "ring64x128"), (16, 14336, 8192, "ring64x64"), (8, 28672, 8192, "skinny"), (16, 28672, 4096, "skinny"), (24, 28672, 8192, "ring64x128"), (25, 28672, 4096, "ring64x128"), (24, 14336, 4096, "ring64x64"), (64, 4096, 4096, "skinny"), (65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
+@pytest.mark.parametrize("M,N,K,want", [(48, 6144, 4096, "ring64x64"), (64, 28672, 4096, "ring64x128"), (24, 28672, 4096, "skinny"), (64, 5120, 11008, "ring64x64"), (48, 5120, 4096, "ring64x64"), (32, 5120, 11008, "skinny"), (16, 28672, 8192, "ring64x128"), (16, 14336, 8192, "ring64x64"), (8, 28672, 8192, "skinny"), (16, 28672, 4096, "skinny"), (24, 28672, 8192, "ring64x128"), (25, 28672, 4096, "ring64x128"), (24, 14336, 4096, "ring64x64"), (64, 4096, 4096, "skinny"), (65, 4096, 4096, "ring64x64"), (128, 4096, 4096, "ring64x64"), (200, 1000, 2048, "ring64x64"), (256, 4096, 4096, "ring64x64"),
                                         (384, 4096, 14336, "ring64x128"), (512, 4096, 4096, "ring64x128"), (512, 4096, 14336, "ring64x128"), (500, 4000, 1152, "ring64x128"),
                                         (128, 28672, 4096, "ring128"), (512, 28672, 4096, "sp256"), (1024, 1024, 8192, "ring64x64"), (2048, 1024, 8192, "ring64x128"),
                                         (640, 2048, 4096, "ring64x128"), (4096, 1024, 8192, "ring128")])

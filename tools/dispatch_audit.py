@@ -18,6 +18,10 @@ if "--small" in sys.argv:            # the decode-like end: the weight-streaming
     Ms = [1, 8, 16, 17, 24, 32, 33, 40, 48, 64]
 Ns = [512, 1024, 2048, 4096, 6144, 8192, 14336, 28672]
 Ks = [1024, 4096, 8192] if not quick else [4096]
+for a_ in sys.argv:                 # --ks=14336,28672  --ns=4096,8192
+    if a_.startswith("--ks="): Ks = [int(v) for v in a_[5:].split(",")]
+    if a_.startswith("--ns="): Ns = [int(v) for v in a_[5:].split(",")]
+    if a_.startswith("--ms="): Ms = [int(v) for v in a_[5:].split(",")]
 dev = torch.device("cuda:0")
 bad = []
 for K in Ks:
