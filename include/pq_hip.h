@@ -132,7 +132,8 @@ size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K);
  * runs along rows).  For the column-sharded configuration (SURVEY.md §8(e) option 1): the ranks' yt shards [N/G, M] are row
  * blocks of yt, so the all-gather is contiguous and needs no layout pass (pq_allgather_rows_t in pq_rccl.h).
  * Arguments as pq_qlinear_s8 (a, a_scale: activation codes [M, K] and token scales; b, b_scale: weight codes [N, K] and
- * channel scales); workspace per pq_qlinear_t_workspace_bytes(M, N, K). */
+ * channel scales); workspace per pq_qlinear_t_workspace_bytes(M, N, K).  With few tokens (where pq_qlinear_s8 would run its
+ * weight-streaming kernel) the product is computed in the normal orientation and only STORED transposed. */
 size_t pq_qlinear_t_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
                         const float* b_scale, const void* bias, void* yt, int64_t ldyt, int32_t out_dtype, int64_t M,

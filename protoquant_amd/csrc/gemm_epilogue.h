@@ -25,12 +25,15 @@ __device__ __forceinline__ bool epi_rows_storable(const EpiArgs& e, const void* 
 // The transposed product y^T = Wq . xq^T (pq_qlinear_s8_t: the GEMM's rows are output channels n, its columns tokens m) must
 // still round as QSPEC E2-E3 say — the TOKEN scale first — so the column scale is applied first and the bias runs along rows.
 constexpr int32_t EPI_COL_FIRST = 1, EPI_BIAS_ROWS = 2;
+// EPI_STORE_T (the weight-streaming kernel only, alone): the product is computed in its normal orientation — tokens as the narrow side, QSPEC as written — and STORED
+// transposed, y[n * ldy + m]: pq_qlinear_s8_t with few tokens (its swapped form would hand the tile kernels a 16-column problem).
+constexpr int32_t EPI_STORE_T = 4;
 // The two bits only ever travel together: 0 (y = x.W^T: row scale first, bias along columns) or the transposed form (column scale
 // first; a bias, if any, along rows).  The staged epilogue dispatches on that pairing (PQ_EPI_STAGED_DISPATCH), the direct / split-K /
 // skinny / generic epilogues read the bits one by one: any other combination would round differently on interior and edge tiles, so
 // every launcher checks epi_flags_valid() (pq_api.hip: run_gemm) and nothing else constructs flags.
 constexpr bool epi_flags_valid(int32_t flags, bool has_bias) {
-    return flags == 0 || (flags == EPI_COL_FIRST && !has_bias) || (flags == (EPI_COL_FIRST | EPI_BIAS_ROWS) && has_bias);
+    return flags == 0 || flags == EPI_STORE_T || (flags == EPI_COL_FIRST && !has_bias) || (flags == (EPI_COL_FIRST | EPI_BIAS_ROWS) && has_bias);
 }
 
 template <int OUT> struct OutElem { using type = typename Elem<OUT>::store_t; };

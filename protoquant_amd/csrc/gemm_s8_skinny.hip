@@ -194,6 +194,11 @@ __global__ __launch_bounds__(1024) void gemm_s8_skinny(const int8_t* __restrict_
             }
             o[j] = epi_convert<OUT>(sum[j], as, bs, bf, has_bias, epi.flags & EPI_COL_FIRST);
         }
+        if (epi.flags & EPI_STORE_T) {                    // y^T[n][m]: four rows of the transposed output, one element each (the whole output is M x N <= 64 x N elements)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (nb + j < N) y[(int64_t)(nb + j) * epi.ldy + m] = o[j];
+            continue;
+        }
         O* dst = y + (int64_t)m * epi.ldy + nb;
         const bool vec = (nb + 3 < N) && ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(O) - 1)) == 0);
         if (vec) {

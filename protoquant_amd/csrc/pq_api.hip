@@ -524,6 +524,21 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
         (M > 0 && !a_scale) || (N > 0 && !b_scale))
         return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_t: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldyt=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldyt);
     if (M == 0 || N == 0) return PQ_OK;
+    {   // few tokens: the swapped form below would be a 16-column problem for the tile kernels (16 x 4096 x 4096: 23 us); the weight-streaming kernel computes the
+        // product in its normal orientation and stores it transposed (5.8 us).  Same arithmetic as pq_qlinear_s8: same bits.
+        Range range_("pq:qlinear_s8_t (K3+K4, streaming)");
+        const Variant f = forced_variant();
+        if ((f == V_AUTO || f == V_SKINNY) && pick_variant(a, lda, b, ldb, M, N, K) == V_SKINNY) {
+            pq::EpiArgs e{a_scale, b_scale, bias, yt, ldyt, pq::EPI_STORE_T};
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            switch (out_dtype) {
+                case PQ_BF16: run_gemm<PQ_BF16>(V_SKINNY, a, lda, b, ldb, e, M, N, K, st); break;
+                case PQ_FP16: run_gemm<PQ_FP16>(V_SKINNY, a, lda, b, ldb, e, M, N, K, st); break;
+                default: run_gemm<PQ_F32>(V_SKINNY, a, lda, b, ldb, e, M, N, K, st); break;
+            }
+            return check_launch("pq_qlinear_s8_t");
+        }
+    }
     pq::EpiArgs epi{b_scale, a_scale, bias, yt, ldyt, pq::EPI_COL_FIRST | (bias ? pq::EPI_BIAS_ROWS : 0)};
     return qlinear_core("pq_qlinear_s8_t", b, ldb, a, lda, epi, out_dtype, N, M, K, workspace, workspace_bytes, stream);
 }

@@ -1373,3 +1373,24 @@ def test_padded_k_module_is_graph_capturable(pq):
     x.copy_(torch.randn(64, 1000, device="cuda").to(torch.bfloat16))
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), m(x).view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (16, 4096, 4096), (16, 777, 512), (40, 4100, 1024), (64, 4096, 14336), (24, 28672, 4096), (33, 6144, 4096)])
+def test_transposed_output_with_few_tokens(pq, M, N, K):
+    """pq_qlinear_s8_t with few tokens: the weight-streaming kernel computes the product in its normal orientation and stores it transposed (the swapped form would be a
+    16-column problem for the tile kernels: 16 x 4096 x 4096 took 23 us, now 5.8) — yt[n][m] == y[m][n] bit for bit, every output type, with bias, into a padded buffer."""
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    b = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    xs = torch.rand(M, device="cuda", generator=g) * 0.02 + 1e-3
+    ws = torch.rand(N, device="cuda", generator=g) * 0.002 + 1e-4
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        for bias in (None, torch.randn(N, device="cuda", generator=g).to(dtype)):
+            y = pq.qlinear_s8(a, xs, b, ws, bias, dtype)
+            yt = pq.qlinear_s8_t(a, xs, b, ws, bias, dtype)
+            assert yt.shape == (N, M) and torch.equal(yt.t().contiguous(), y), (dtype, bias is not None)
+            big = torch.full((N + 2, M + 3), 7.0, dtype=dtype, device="cuda")
+            pq.qlinear_s8_t(a, xs, b, ws, bias, dtype, out=big[1:N + 1, 2:M + 2])
+            assert torch.equal(big[1:N + 1, 2:M + 2].t().contiguous(), y)
+            big[1:N + 1, 2:M + 2] = 7.0
+            assert bool((big == 7.0).all())
