@@ -475,7 +475,11 @@ static void launch_rowwise_vec(int vpt, const void* x, int64_t rows, int nvec, i
         case 2: quant_rowwise_vec<DT, 2, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
         case 4: quant_rowwise_vec<DT, 4, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
         case 8: quant_rowwise_vec<DT, 8, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
-        default: quant_rowwise_vec<DT, 16, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        case 16: quant_rowwise_vec<DT, 16, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale); break;
+        default:      // 32 vectors per lane (256 lanes per row only): rows up to 65 536 bf16 / 32 768 f32 columns stay in registers (128 VGPRs of raw data)
+            if constexpr (TPR == 256) quant_rowwise_vec<DT, 32, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale);
+            else quant_rowwise_vec<DT, 16, TPR><<<grid, block, k1_lds, st>>>(xb, rows, nvec, ldx_bytes, q, ldq, scale);
+            break;
     }
 }
 
@@ -485,7 +489,7 @@ void quant_rowwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
     constexpr int EPV = 16 / Elem<DT>::kBytes;
     // (cols == 0 goes to the generic kernel: it touches no element and writes scale = 1)
     const bool vec_ok = cols > 0 && (cols % EPV == 0) && (ldx % EPV == 0) && aligned(x, 16) && (ldq % EPV == 0) &&
-                        aligned(q, EPV) && cols / EPV <= 256 * 16;
+                        aligned(q, EPV) && cols / EPV <= 256 * 32;
     if (vec_ok) {
         const int nvec = (int)(cols / EPV);
         auto pow2 = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };

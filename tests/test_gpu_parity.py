@@ -1394,3 +1394,18 @@ def test_transposed_output_with_few_tokens(pq, M, N, K):
             assert torch.equal(big[1:N + 1, 2:M + 2].t().contiguous(), y)
             big[1:N + 1, 2:M + 2] = 7.0
             assert bool((big == 7.0).all())
+
+
+@pytest.mark.parametrize("rows,cols,code", [(64, 32768, 0), (40, 40960, 0), (33, 53248, 0), (16, 65536, 1), (8, 65544, 0), (24, 28672, 2), (12, 32768, 2), (5, 32776, 2)])
+def test_rowwise_quant_of_very_wide_rows(pq, rows, cols, code):
+    """Rows past the round-3 register-resident limit (32 768 bf16 / 16 384 f32 columns): up to 65 536 / 32 768 columns the row still stays in registers (32 vectors per
+    lane: 4096 x 53248 bf16 352 -> 118 us), beyond that the generic kernel takes over — same codes and scales as the oracle either way, incl. a NaN row and an all-zero row."""
+    g = torch.Generator(device="cuda"); g.manual_seed(cols)
+    x = (torch.randn(rows, cols, device="cuda", generator=g) * 3).to(TD[code])
+    x[1] = 0
+    x[2, cols - 1] = float("nan")
+    x[3, cols // 2] = 1e4
+    q = pq.quantize(x)
+    wq, ws = Q.quantize(x.cpu().numpy() if code == 2 else bits(x), code, 1)
+    assert np.array_equal(q.int_data.cpu().numpy(), wq)
+    assert np.array_equal(bits(q.scale), ws.view(np.uint32))
