@@ -14,14 +14,16 @@ compute step, and the script asserts GEMM + K1 <= 1.05 x step.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU — or by bench.py itself when no launcher set WORLD_SIZE: it then starts
 the same torch.distributed.run command as child processes before touching the GPU and relays rank 0's line): north_star's split — the weight is column-sharded
-over the ranks (N/G output channels each), the activation replicated, and ONE RCCL all-gather of the bf16 output shards per step
-rebuilds y[M, N] (libpq_rccl.so: ncclAllGather + layout kernel); the whole job is ONE M x N x K qlinear (strong scaling).  The
-data-parallel figure (every rank its own batch, replicated weights, no collective) is reported under "dp"; `--mode dp` makes it the
-main line.
+over the ranks (N/G output channels each), the activation replicated, and ONE all-gather of the bf16 output shards per step rebuilds y[M, N]; the whole job is
+ONE M x N x K qlinear (strong scaling).  Every exchange form the repo holds is timed as a LEG by the same protocol (run_tp): torch.distributed's all-gather (rows /
+transposed shards) first, then libpq_rccl.so's plain gather + layout kernel, transposed shards (no layout pass) and 2 / 4 / 8 row blocks overlapped with the GEMM,
+each captured whole into the step's hipGraph and each under its own watchdog.  Every leg is VERIFIED (each rank compares the y it holds, bit for bit, with the
+unsharded qlinear it computes itself); the headline `value` is the fastest verified leg, all legs are listed under `legs`.  The data-parallel figure (every rank its
+own batch, replicated weights, no collective) is reported under "dp"; `--mode dp` makes it the main line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (GEMM kernel vs the
-5.033 POPS dense int8 MFMA peak, timed live with HIP events) and `cpu_baseline` (the QSPEC pipeline
-around torch._int_mm on the host cores, rank 0 / N=1 only).
+5.033 POPS dense int8 MFMA peak, timed live with HIP events), `cpu_baseline` (the QSPEC pipeline around torch._int_mm on the host
+cores, rank 0, after the timed regions, at every world size) and `verified`.
 """
 import argparse
 import json
@@ -54,7 +56,6 @@ def parse():
     ap.add_argument("--warmup-seconds", type=float, default=1.5, help="untimed warm-up by time after the --warmup steps")
     ap.add_argument("--torch-gather", action="store_true", help="tp: exchange through torch.distributed instead of libpq_rccl.so")
     ap.add_argument("--no-dp-leg", action="store_true", help="tp: skip the extra dp figure")
-    ap.add_argument("--tp-transposed-leg", action="store_true", help="tp (RCCL): also time the transposed-shard form (pq_qlinear_s8_t + contiguous all-gather)")
     ap.add_argument("--no-consistency-check", action="store_true")
     ap.add_argument("--layers", type=int, default=32, help="llama8b workload: decoder layers (32 = the model)")
     ap.add_argument("--no-layer-fusion", action="store_true", help="llama8b workload: skip fuse_llama_layers (stock norms, separate q/k/v GEMMs)")
@@ -69,9 +70,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--native-timeout", type=float, default=120.0,
-                    help="tp over RCCL with > 1 rank: seconds the native exchange path (libpq_rccl.so, graph-captured) may take before the line measured "
-                         "with torch.distributed's all-gather just before is printed instead (a multi-GPU run is never lost to a hung collective)")
-    ap.add_argument("--safety-net", action="store_true", help="take the torch.distributed measurement + watchdog also at 1 rank (tests)")
+                    help="tp over RCCL: seconds EACH leg that drives the native exchange (libpq_rccl.so) may take; when one does not finish, the fastest verified leg "
+                         "among those that did (the torch.distributed legs run first) is printed with \"native_exchange\": \"hung\" (a multi-GPU run is never lost to a hung collective)")
     ap.add_argument("--simulate-native-hang", action="store_true", help="tests: the native path never returns (the watchdog must print the safe line)")
     return ap.parse_args()
 
@@ -603,6 +603,489 @@ def run_llama70b_shard(args):
                       "cpu_baseline": None})
 
 
+class _Watchdog:
+    """A collective that hangs cannot be cancelled from inside the process.  Every leg that drives the native exchange (a second RCCL communicator inside
+    libpq_rccl.so) therefore runs with this timer armed FOR THAT LEG ONLY (armed just before the leg's first native collective, cancelled when the leg's result is
+    recorded — ADVICE r4: the round-4 timer covered the whole rest of the benchmark): if it fires, rank 0 prints the best line the legs that DID finish and verify
+    support, with top-level "native_exchange": "hung" and the leg's name, and every rank leaves with status 0 (a fresh exit, no re-exec)."""
+
+    def __init__(self, rank, compose):
+        import threading
+        self._threading, self.rank, self.compose = threading, rank, compose
+        self.lock, self.done, self.timer, self.leg = threading.Lock(), False, None, None
+
+    def arm(self, leg, seconds):
+        self.disarm()
+        self.leg = leg
+        self.timer = self._threading.Timer(seconds, self._fire, args=(leg, seconds))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self, leg, seconds):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            line = None
+            try:
+                line = self.compose(hung_leg=leg, timeout=seconds)
+            except Exception as e:
+                print(f"[bench] rank {self.rank}: composing the line after a hang failed: {e}", file=sys.stderr)
+            print(f"[bench] rank {self.rank}: the native RCCL leg '{leg}' did not finish within {seconds:.0f} s — "
+                  + ("printing the best verified line of the legs that finished" if line else "no finished leg either"), file=sys.stderr)
+            if self.rank == 0 and line is not None:
+                emit_json(line)
+            sys.stderr.flush()
+            os._exit(0 if line is not None else 3)
+
+
+def run_tp(args, world, rank, dev, dist):
+    """north_star's split of the headline qlinear over `world` ranks (one process per GPU): W column-sharded over the output channels, the activation
+    replicated (every rank runs K1 itself), ONE all-gather of the bf16 output shards per step.  The repo holds several forms of that exchange (DESIGN.md §6);
+    each is a LEG here: timed by the same protocol (W warm-up steps + warm-up by time, R blocks of exactly K steps between barrier + synchronize, max over ranks,
+    median block), replayed whole from a hipGraph where it can be captured, and VERIFIED — every rank compares the y it ends up holding, bit for bit, with the
+    unsharded qlinear it computes itself from the full weight.  The headline `value` is the fastest leg that finished AND verified; every leg is listed under
+    `legs`.  Legs:
+      torch_plain / torch_transposed   torch.distributed's own all-gather (the path every PyTorch job uses), issued eagerly behind the compute graph — measured
+                                       FIRST: they are the line a hung native collective falls back to
+      native_plain                     pq_allgather_cols_v: ncclAllGather into a stacked workspace + layout kernel
+      native_transposed                pq_qlinear_s8_t + pq_allgather_rows_t: transposed shards, ONE contiguous ncclAllGather, no layout pass (SURVEY.md §8(e) option 1)
+      native_overlap{2,4,8}            row blocks: each block's exchange (pq_allgather_cols_rows_async, the communicator's side stream) runs under the next block's
+                                       GEMM; pq_comm_join at the end of the step (SURVEY.md:303 "chunked along M and overlapped with K3")"""
+    import protoquant_amd as pq
+    from protoquant_amd import _lib as L
+    from protoquant_amd.sharded import shard_bounds, gather_columns
+    lib = L.lib()
+    M, N, K = args.M, args.N, args.K
+    st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
+    med = lambda v: sorted(v)[len(v) // 2]                   # noqa: E731
+    K_steps, R, PG = max(1, args.steps), max(1, args.repeats), 20
+    lo, hi = shard_bounds(N, world, rank)
+    n_local = hi - lo
+    equal = N % world == 0
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_min(flag):
+        t = torch.tensor([1 if flag else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def all_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def ev_us(g, n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); b.synchronize()
+        return a.elapsed_time(b) * 1e3 / n
+
+    # ---- synthetic data (SURVEY §8d), seeded on the CPU generator so every rank and every box agree.  Every rank holds the FULL weight as well: it is what
+    # the verification computes the unsharded qlinear from (per-channel quantisation is row-local: the rank's shard is a row block of the full codes).
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    gw = torch.Generator().manual_seed(4321)
+    qw = pq.quantize((torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16).to(dev))
+    wq_full, ws_full = qw.int_data, qw.scale
+    wq, ws = wq_full[lo:hi].clone(), ws_full[lo:hi].clone()       # the rank's shard (own allocations: aligned bases for any split)
+    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
+    xs = torch.empty((M,), dtype=torch.float32, device=dev)
+    y_loc = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
+    yt_loc = torch.empty((n_local, M), dtype=torch.bfloat16, device=dev)
+    y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    yt_full = torch.empty((N, M), dtype=torch.bfloat16, device=dev)
+
+    def wspace(nbytes):
+        return torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev), nbytes
+
+    def k1():
+        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
+
+    def gemm_rows(m0, m1, wsp, wb, w=None, wsc=None, out=None, ldo=None, n=None):
+        w = wq if w is None else w; wsc = ws if wsc is None else wsc
+        out = y_loc if out is None else out; n = n_local if n is None else n; ldo = n if ldo is None else ldo
+        L.check(lib.pq_qlinear_s8(xq.data_ptr() + m0 * K, K, xs.data_ptr() + 4 * m0, w.data_ptr(), K, wsc.data_ptr(), None,
+                                  out.data_ptr() + 2 * m0 * ldo, ldo, 0, m1 - m0, n, K, wsp.data_ptr() if wb else None, wb, st()), "pq_qlinear_s8")
+    wsp_l, wb_l = wspace(lib.pq_qlinear_workspace_bytes(M, n_local, K))
+    wsp_t, wb_t = wspace(lib.pq_qlinear_t_workspace_bytes(M, n_local, K))
+
+    def k3():
+        gemm_rows(0, M, wsp_l, wb_l)
+
+    def k3t():
+        L.check(lib.pq_qlinear_s8_t(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, yt_loc.data_ptr(), M, 0,
+                                    M, n_local, K, wsp_t.data_ptr() if wb_t else None, wb_t, st()), "pq_qlinear_s8_t")
+
+    # the unsharded qlinear on this rank: the bits every leg must reproduce
+    y_ref = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    wsp_f, wb_f = wspace(lib.pq_qlinear_workspace_bytes(M, N, K))
+    k1(); gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)
+    torch.cuda.synchronize()
+    y_ref_bits = y_ref.view(torch.int16)
+
+    # ---- per-kernel durations (no collective): the rank's shard GEMM (the `roofline` kernel), K1 cache-resident and HBM-fed, the compute step
+    gk1, gk3, gst = graph_of(k1, PG), graph_of(k3, PG), graph_of(lambda: (k1(), k3()), PG)
+    for g_ in (gk1, gk3, gst):
+        g_.replay()
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + min(args.warmup_seconds, 1.0)
+    while time.perf_counter() < t_end:
+        gst.replay(); torch.cuda.synchronize()
+    tk1, tk3, tst = [], [], []
+    for _ in range(max(R, 20)):
+        tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
+    t_gemm, t_k1_hot, t_stepc = med(tk3), med(tk1), med(tst)
+    n_rot = max(2, -(-600 * 2**20 // (3 * M * K)))
+    rot = [(torch.randn(M, K, device=dev).to(torch.bfloat16), torch.empty((M, K), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
+           for _ in range(n_rot)]
+
+    def k1_rot():
+        for xr_, qr_, sr_ in rot:
+            L.check(lib.pq_quant_rowwise(xr_.data_ptr(), 0, M, K, K, qr_.data_ptr(), K, sr_.data_ptr(), st()), "pq_quant_rowwise")
+    g_rot = graph_of(k1_rot, 2)
+    g_rot.replay(); torch.cuda.synchronize()
+    t_k1 = med([ev_us(g_rot, 2 * n_rot) for _ in range(15)])
+    del rot, g_rot, gk1, gk3, gst
+    consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)
+    if not consistent:      # several ranks share one host and one power envelope: a multi-GPU line is never lost to this check, it carries the flag
+        print(f"[bench] WARNING (rank {rank}): GEMM {t_gemm:.2f} us + K1 {t_k1_hot:.2f} (cache-resident) .. {t_k1:.2f} us (HBM) vs compute step {t_stepc:.2f} us", file=sys.stderr)
+
+    # ---- the legs
+    class Leg:
+        def __init__(self, name, exchange, compute, comm, result, clear, native, capturable, what, chunks=1):
+            self.name, self.exchange, self.compute, self.comm, self.result, self.clear = name, exchange, compute, comm, result, clear
+            self.native, self.capturable, self.what, self.chunks = native, capturable, what, chunks
+
+        def step(self):
+            self.compute(); self.comm()
+
+    def tg_plain():
+        y_full.copy_(gather_columns(y_loc, N))
+
+    def tg_t():
+        if equal:
+            dist.all_gather_into_tensor(yt_full.view(-1), yt_loc.view(-1))
+        else:
+            from protoquant_amd.sharded import gather_rows_t
+            yt_full.copy_(gather_rows_t(yt_loc, N))
+    clear_rows = lambda: (y_full.zero_(), y_loc.zero_())       # noqa: E731
+    clear_t = lambda: (yt_full.zero_(), yt_loc.zero_())        # noqa: E731
+    legs = [Leg("torch_plain", f"torch.distributed all_gather_into_tensor ({args.backend}) + layout pass", lambda: (k1(), k3()), tg_plain, lambda: y_full, clear_rows, False, False,
+                "K1 + shard GEMM from a hipGraph, the collective issued eagerly behind each step"),
+            Leg("torch_transposed", f"pq_qlinear_s8_t + torch.distributed all_gather_into_tensor ({args.backend}) straight into y^T[N, M], no layout pass", lambda: (k1(), k3t()), tg_t,
+                lambda: yt_full.t(), clear_t, False, False, "transposed shards: the gather is contiguous; y is the column-major view y^T.t() (same bits)")]
+    rg, native_state = None, "not_attempted"
+    want_native = args.backend == "nccl" and not args.torch_gather
+    results, order = {}, []
+    shared = {"native_state": native_state}
+
+    def leg_model(leg, t_comp):
+        """DESIGN.md §6's model of this leg for this G: the rank's MEASURED compute, the all-gather at the point-to-point link rate (every peer's shard arrives over its
+        own xGMI link, ~153 GB/s each, all links busy at once) and, for the row-major forms, the layout pass (reads + writes 2 M N bytes at ~5 TB/s)."""
+        XGMI_LINK_GBS, LAYOUT_TBS = 153.0, 5.0
+        shard_bytes = 2 * M * n_local
+        ag = shard_bytes / (XGMI_LINK_GBS * 1e3) if world > 1 else 2 * M * N / (LAYOUT_TBS * 1e6)     # world 1: a device-local copy
+        lay = 0.0 if "transposed" in leg.name else 2 * (2 * M * N) / (LAYOUT_TBS * 1e6)
+        C = leg.chunks
+        if C > 1:           # pipeline of C row blocks: the first block's GEMM and the last block's exchange are exposed, the rest runs at the slower of the two
+            c, e = (t_comp - t_k1_hot) / C, (ag + lay) / C
+            step = t_k1_hot + c + (C - 1) * max(c, e) + e
+        else:
+            step = t_comp + ag + lay
+        return {"compute_us": round(t_comp, 2), "allgather_us": round(ag, 2), "layout_pass_us": round(lay, 2), "step_us": round(step, 2),
+                "assumptions": f"per-rank shard {shard_bytes} B over one direct xGMI link per peer at {XGMI_LINK_GBS:.0f} GB/s, all {max(world - 1, 1)} links concurrently; "
+                               f"layout pass at {LAYOUT_TBS:.0f} TB/s; " + (f"{C} row blocks, exchange of block i under the GEMM of block i+1" if C > 1 else "no overlap of exchange and compute")
+                               + " (DESIGN.md §6)"}
+
+    def run_leg(leg):
+        """time + verify one leg; returns its record"""
+        rec = {"exchange": leg.exchange, "what": leg.what, "native": leg.native, "verified": False}
+        S, g_main, g_rem, in_graph = 1, None, None, False
+        leg.step(); torch.cuda.synchronize()                      # (allocates exchange workspaces outside any capture)
+        if leg.capturable and not args.no_graph:
+            try:
+                S = min(K_steps, 20)
+                g_main = graph_of(leg.step, S)
+                if K_steps % S:
+                    g_rem = graph_of(leg.step, K_steps % S)
+                in_graph = True
+            except Exception as e:
+                print(f"[bench] leg {leg.name}: capturing the exchange into the step graph failed ({e}); collective issued eagerly behind each step", file=sys.stderr)
+            in_graph = all_min(in_graph)                            # every rank must replay the same thing
+            if not in_graph:
+                g_main = g_rem = None
+        g_comp = None
+        if not in_graph:
+            S = 1
+            if not args.no_graph:
+                g_comp = graph_of(leg.compute, 1)
+
+        def run_steps(n):
+            if in_graph:
+                for _ in range(n // S):
+                    g_main.replay()
+                if n % S:
+                    (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(leg.step, n % S)).replay()
+                return
+            for _ in range(n):
+                if g_comp is not None:
+                    g_comp.replay()
+                else:
+                    leg.compute()
+                leg.comm()
+        run_steps(args.warmup)
+        fence()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.warmup_seconds:
+            run_steps(K_steps)
+            torch.cuda.synchronize()
+        fence()
+        blocks, host_enq = [], []
+        for _ in range(R):
+            fence()
+            t0 = time.perf_counter()
+            run_steps(K_steps)
+            host_enq.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            blocks.append(all_max(time.perf_counter() - t0))
+        blocks.sort()
+        dt = blocks[len(blocks) // 2]
+        # verification: outputs cleared, exactly the timed step once more, then every rank compares what it holds with its own unsharded qlinear
+        leg.clear(); torch.cuda.synchronize()
+        run_steps(S if in_graph else 1)
+        torch.cuda.synchronize()
+        got = leg.result()
+        same = tuple(got.shape) == (M, N) and bool(torch.equal(got.contiguous().view(torch.int16), y_ref_bits))
+        rec["verified"] = all_min(same)
+        if not same:
+            print(f"[bench] rank {rank}: leg {leg.name} does NOT reproduce the unsharded qlinear", file=sys.stderr)
+        # the leg's compute alone (K1 + its GEMM launches) and its exchange alone, gap-free from their own graphs where capturable
+        t_comp = t_exch = None
+        try:
+            gc_ = graph_of(leg.compute, PG)
+            gc_.replay(); torch.cuda.synchronize()
+            t_comp = med([ev_us(gc_, PG) for _ in range(9)])
+            del gc_
+            fence()
+            if in_graph:
+                ge_ = graph_of(leg.comm, PG)
+                ge_.replay(); fence()
+                v = med([ev_us(ge_, PG) for _ in range(9)])
+                del ge_
+            else:
+                def ex_eager():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(PG):
+                        leg.comm()
+                    b.record(); b.synchronize()
+                    return a.elapsed_time(b) * 1e3 / PG
+                ex_eager(); fence()
+                v = med([ex_eager() for _ in range(5)])
+            t_exch = all_max(v)
+            fence()
+        except Exception as e:
+            print(f"[bench] leg {leg.name}: compute / exchange-only timing failed: {e}", file=sys.stderr)
+        host_us = med(host_enq) / K_steps * 1e6
+        step_us = dt / K_steps * 1e6
+        rec.update({"value": round(2.0 * M * N * K * K_steps / dt / 1e12, 2), "unit": "TOPS", "ms_per_step": round(dt / K_steps * 1e3, 5),
+                    "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
+                    "collective_in_graph": in_graph,
+                    "launch": (f"hipgraph x{S} steps/replay, exchange captured in the graph" if in_graph else
+                               ("hipgraph x1 step/replay (compute), collective eager behind each step" if g_comp is not None else "eager")),
+                    "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool((not in_graph) and host_us > 0.9 * step_us),
+                    "compute_us": round(t_comp, 2) if t_comp is not None else None, "exchange_us": round(t_exch, 2) if t_exch is not None else None})
+        if t_comp is not None:
+            rec["modelled"] = leg_model(leg, t_comp)
+            rec["measured_minus_modelled_us"] = round(step_us - rec["modelled"]["step_us"], 2)
+        return rec
+
+    def compose(hung_leg=None, timeout=None):
+        """the ONE JSON line from whatever has finished so far (called at the end, or by the watchdog)"""
+        done = {n: results[n] for n in order if n in results}
+        ok = [n for n in done if done[n]["verified"] and "value" in done[n]]
+        timed = [n for n in done if "ms_per_step" in done[n]]
+        if not timed:
+            return None
+        head = min(ok, key=lambda n: done[n]["ms_per_step"]) if ok else None
+        h = done[head] if head else done[timed[0]]          # (no verified leg: the line carries value 0 and verified = false)
+        variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
+        kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
+                 "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
+        if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
+            kname += " split-K + splitk_reduce_epilogue"
+        gemm_ops, gemm_bytes, k1_bytes = 2.0 * M * n_local * K, M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local), 3 * M * K + 4 * M
+        out = {
+            "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
+            "value": h["value"] if head else 0.0, "unit": "TOPS", "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
+            "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+            "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
+                       "parallelism": f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant",
+                       "headline_leg": head, "exchange": h["exchange"], "launch": h["launch"], "collective_in_graph": h["collective_in_graph"],
+                       "rccl_ranks": shared.get("rccl_ranks", dist.get_world_size()), "native": bool(h["native"]),
+                       "repeats": R, "timed": f"per leg: median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks); headline = the fastest "
+                                              "leg that finished AND reproduced the unsharded qlinear bit for bit on every rank",
+                       "warmup_seconds": args.warmup_seconds, "gemm_variant": variant},
+            "verified": bool(head is not None), "ms_per_step_min": h["ms_per_step_min"], "ms_per_step_max": h["ms_per_step_max"],
+            "legs": done, "native_exchange": "hung" if hung_leg else shared["native_state"],
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(gemm_ops / t_gemm / 1e6, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                         "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4), "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_min": round(min(tk3), 2),
+                         "how": f"the rank's shard GEMM {M}x{n_local}x{K}: median of {len(tk3)} hipGraph replays of {PG} back-to-back launches, HIP events on the launch stream",
+                         "traffic": None, "algorithmic_bytes": gemm_bytes},
+            "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4), "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes,
+                           "how": f"gap-free hipGraph replays rotating over {n_rot} distinct input/output pairs: every launch is HBM-fed",
+                           "in_step_us": round(t_stepc - t_gemm, 2), "cache_resident_replay_us": round(t_k1_hot, 2)},
+            "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
+            "host_enqueue_us_per_step": h["host_enqueue_us_per_step"], "host_bound": h["host_bound"],
+            "compute_us": h["compute_us"], "exchange_us": h["exchange_us"], "exchange_bytes_received_per_rank": 2 * M * (N - n_local),
+            "cpu_baseline": shared.get("cpu_baseline"),
+        }
+        if "modelled" in h:
+            out["modelled"] = h["modelled"]
+            out["config"]["modelled_step_us"] = h["modelled"]["step_us"]
+            out["measured_minus_modelled_us"] = h["measured_minus_modelled_us"]
+        if "torch_plain" in done and "ms_per_step" in done["torch_plain"]:
+            out["torch_distributed_exchange_ms_per_step"] = done["torch_plain"]["ms_per_step"]
+        if "dp" in shared:
+            out["dp"] = shared["dp"]
+        if hung_leg:
+            out["hung_leg"] = hung_leg
+            out["fallback"] = (f"the native exchange leg '{hung_leg}' (libpq_rccl.so) did not finish within {timeout:.0f} s: the line is the fastest verified leg among those that "
+                               "finished before it")
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                tr = json.load(open(tj))
+                if (M, n_local, K) == (4096, 4096, 4096):
+                    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr.get("gemm_hbm_bytes_per_launch"), tr.get("source")
+                else:       # the rank's shard GEMM is another shape: PMC passes per shard width (tools/pmc_traffic_shards.sh)
+                    out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch_by_shape", {}).get(f"{M}x{n_local}x{K}")
+                    out["roofline"]["traffic_source"] = tr.get("source_by_shape") if out["roofline"]["traffic"] else None
+            except Exception:
+                pass
+        return out
+
+    dog = _Watchdog(rank, compose)
+    # the torch.distributed legs first: the net under everything that follows
+    for leg in legs:
+        order.append(leg.name)
+        try:
+            results[leg.name] = run_leg(leg)
+        except Exception as e:
+            print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
+            results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": False}
+
+    if want_native:
+        def boot():
+            from protoquant_amd.sharded import RcclColumnGather
+            return RcclColumnGather()
+        dog.arm("communicator bootstrap", args.native_timeout)
+        if args.simulate_native_hang:
+            while True:
+                time.sleep(1.0)
+        try:
+            rg = boot()
+        except Exception as e:
+            print(f"[bench] native RCCL exchange unavailable ({e})", file=sys.stderr)
+            rg = None
+        if not all_min(rg is not None):          # every rank must take the same path
+            rg = None
+        dog.disarm()
+        shared["native_state"] = "ok" if rg is not None else "unavailable"
+    if rg is not None:
+        shared["rccl_ranks"] = rg.comm_ranks()
+        nat = [Leg("native_plain", "libpq_rccl.so pq_allgather_cols_v (ncclAllGather + layout kernel)", lambda: (k1(), k3()), lambda: rg.gather_into(y_loc, y_full, N),
+                   lambda: y_full, clear_rows, True, True, "the whole step (K1, shard GEMM, ncclAllGather, layout kernel) in one hipGraph"),
+               Leg("native_transposed", "libpq_rccl.so pq_qlinear_s8_t + pq_allgather_rows_t (one contiguous ncclAllGather, no layout kernel)", lambda: (k1(), k3t()),
+                   lambda: rg.gather_t(yt_loc, N, out=yt_full), lambda: yt_full.t(), clear_t, True, True,
+                   "transposed shards gathered in place; y is the column-major view y^T.t() (same bits)")]
+        for C in (2, 4, 8):
+            if M // C < 256:
+                continue
+            bounds = [shard_bounds(M, C, c) for c in range(C)]
+            wsp_c, wb_c = wspace(max(lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K) for m0, m1 in bounds))
+
+            def comp_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
+                k1()
+                for m0, m1 in bounds:
+                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
+
+            def comm_c(bounds=bounds):
+                for m0, m1 in bounds:
+                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
+                rg.join(dev)
+
+            def step_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
+                k1()
+                for m0, m1 in bounds:
+                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
+                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
+                rg.join(dev)
+            lg = Leg(f"native_overlap{C}", f"libpq_rccl.so pq_allgather_cols_rows_async x{C} row blocks on the communicator's side stream + pq_comm_join", comp_c, comm_c,
+                     lambda: y_full, clear_rows, True, True, f"{C} row blocks: the exchange of block i runs under the GEMM of block i+1; the whole step in one hipGraph", chunks=C)
+            lg.step = step_c
+            nat.append(lg)
+        for leg in nat:
+            order.append(leg.name)
+            dog.arm(leg.name, args.native_timeout)
+            try:
+                results[leg.name] = run_leg(leg)
+            except Exception as e:
+                print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
+                results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": True}
+            dog.disarm()
+            if not all_min("error" not in results[leg.name]):      # a leg that raised on one rank left the ranks out of step: stop trying native legs
+                shared["native_state"] = "failed"
+                break
+
+    if not args.no_dp_leg:
+        # extra key: the same ranks as independent replicas over tokens (weak scaling, replicated weights, no collective), short
+        try:
+            gd = graph_of(lambda: (k1(), gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)), PG)
+            for _ in range(10):
+                gd.replay()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(25):
+                gd.replay()
+            torch.cuda.synchronize()
+            d = all_max(time.perf_counter() - t0)
+            shared["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / d / 1e12, 2), "unit": "TOPS", "scaling": "weak",
+                            "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
+        except Exception as e:
+            print(f"[bench] dp leg failed: {e}", file=sys.stderr)
+    if rank == 0 and not args.no_cpu_baseline:
+        # after every timed region; the other ranks wait at the barrier below (they hold no GPU work)
+        try:
+            shared["cpu_baseline"] = cpu_baseline(M, N, K, budget_s=20.0)
+        except Exception as e:
+            print(f"[bench] cpu baseline failed: {e}", file=sys.stderr)
+    with dog.lock:
+        if dog.done:
+            return
+        dog.done = True
+        dog.disarm()
+        if rank == 0:
+            emit_json(compose())
+    if rg is not None:
+        try:
+            rg.close()
+        except Exception:
+            pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 _JSON_FD = None
 
 
@@ -687,71 +1170,39 @@ def main():
         else:
             dist.init_process_group(args.backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # N > 1: north_star's split — W column-sharded over the ranks, the activation replicated, ONE RCCL all-gather of the
+    # bf16 output shards per step (strong scaling: the whole job is ONE M x N x K qlinear): run_tp.  --mode dp: every rank runs
+    # the whole qlinear on its own batch (weak scaling, no collective): below; reported as the extra key "dp" in tp runs.
+    mode = args.mode if args.mode != "auto" else ("tp" if world > 1 else "dp")
+    if mode == "tp":
+        return run_tp(args, world, rank, dev, dist)
 
     import protoquant_amd as pq
     from protoquant_amd import _lib as L
-    from protoquant_amd.sharded import shard_bounds
     lib = L.lib()
 
     M, N, K = args.M, args.N, args.K
-    # N > 1: north_star's split — W column-sharded over the ranks, the activation replicated, ONE RCCL all-gather of the
-    # bf16 output shards per step (strong scaling: the whole job is ONE M x N x K qlinear).  --mode dp: every rank runs
-    # the whole qlinear on its own batch (weak scaling, no collective); reported as the extra key "dp" in tp runs.
-    mode = args.mode if args.mode != "auto" else ("tp" if world > 1 else "dp")
-    tp = mode == "tp"
     st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
 
-    def build_step(tp_mode, force_torch=False):
-        """(step_fn, k1_fn, gemm_fn, gather_fn or None, n_local, state) for one rank"""
-        lo, hi = shard_bounds(N, world, rank) if tp_mode else (0, N)
-        n_local = hi - lo
-        # synthetic data (SURVEY §8d): seeded on the CPU generator so every box agrees; dp ranks offset the seed
-        g = torch.Generator().manual_seed(1234 + (0 if tp_mode else rank))
-        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
-        gw = torch.Generator().manual_seed(4321)
-        w = (torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16)[lo:hi]
-        qw = pq.quantize(w.to(dev))                 # one-time weight quantisation (K1 over W's rows)
-        wq, ws = qw.int_data, qw.scale
-        xq = torch.empty((M, K), dtype=torch.int8, device=dev)
-        xs = torch.empty((M,), dtype=torch.float32, device=dev)
-        y = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
-        wbytes = lib.pq_qlinear_workspace_bytes(M, n_local, K)        # 0 for the headline shape; > 0 for narrow shards (split-K)
-        wsp = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+    # synthetic data: seeded on the CPU generator so every box agrees; dp ranks offset the seed
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    gw = torch.Generator().manual_seed(4321)
+    w = (torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16)
+    qw = pq.quantize(w.to(dev))                 # one-time weight quantisation (K1 over W's rows)
+    wq, ws = qw.int_data, qw.scale
+    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
+    xs = torch.empty((M,), dtype=torch.float32, device=dev)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    wbytes = lib.pq_qlinear_workspace_bytes(M, N, K)        # 0 for the headline shape
+    wsp = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
 
-        def k1():
-            L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
+    def k1():
+        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
 
-        def k3():
-            L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
-                                      y.data_ptr(), n_local, 0, M, n_local, K, wsp.data_ptr() if wbytes else None, wbytes, st()), "pq_qlinear_s8")
-        gather, info = None, {}
-        if tp_mode:
-            y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-            rg = None
-            if args.backend == "nccl" and not args.torch_gather and not force_torch:
-                try:                                   # the native exchange; a failure to bootstrap it must not lose the measurement
-                    from protoquant_amd.sharded import RcclColumnGather
-                    rg = RcclColumnGather()
-                    info = {"exchange": "libpq_rccl.so pq_allgather_cols_v (ncclAllGather + layout kernel)", "rccl_ranks": rg.comm_ranks()}
-                except Exception as e:
-                    print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed's all-gather", file=sys.stderr)
-                    rg = None
-                ok = torch.tensor([1 if rg is not None else 0], device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank must take the same path
-                if int(ok.item()) == 0:
-                    rg = None
-            if rg is not None:
-                info["native"] = True
-
-                def gather():
-                    rg.gather_into(y, y_full, N)
-            else:
-                from protoquant_amd.sharded import gather_columns
-                info = {"exchange": f"torch.distributed all_gather_into_tensor ({args.backend}) + layout pass", "rccl_ranks": dist.get_world_size()}
-
-                def gather():
-                    y_full.copy_(gather_columns(y, N))
-        return k1, k3, gather, n_local, info, (x, xq, xs, y, wq, ws, wsp)
+    def k3():
+        L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None,
+                                  y.data_ptr(), N, 0, M, N, K, wsp.data_ptr() if wbytes else None, wbytes, st()), "pq_qlinear_s8")
 
     def fence():
         torch.cuda.synchronize()
@@ -759,130 +1210,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- safety net (tp over RCCL with more than one rank): the native exchange — a second communicator inside libpq_rccl.so, captured into the step's hipGraph —
-    # has never run on more than one GPU in the builder's hands.  A collective that hangs cannot be cancelled from inside the process, so BEFORE it is tried the
-    # same step is measured with torch.distributed's own all-gather, issued eagerly (the path every PyTorch job uses); a watchdog prints THAT line and ends
-    # the rank with status 0 if the native path has not produced its line within --native-timeout seconds.  The line says which one it is (`config.exchange`, `fallback`).
-    import threading
-    net = {"lock": threading.Lock(), "done": False, "line": None, "timer": None}
-    if tp and args.backend == "nccl" and not args.torch_gather and (world > 1 or args.safety_net):
-        try:
-            k1s, k3s, gathers, nls, infos, _keeps = build_step(True, force_torch=True)
-            gs_ = graph_of(lambda: (k1s(), k3s()), 1)
-            gk_ = graph_of(k3s, 20)
-            Ks = max(1, args.steps)
-            for _ in range(max(args.warmup, 20)):
-                gs_.replay(); gathers()
-            fence()
-            bl = []
-            for _ in range(5):
-                fence()
-                t0 = time.perf_counter()
-                for _ in range(Ks):
-                    gs_.replay(); gathers()
-                torch.cuda.synchronize()
-                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                bl.append(float(tt.item()))
-            bl.sort()
-            sdt = bl[len(bl) // 2]
-            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            gk_.replay(); torch.cuda.synchronize()
-            a_.record(); gk_.replay(); b_.record(); b_.synchronize()
-            tg = a_.elapsed_time(b_) * 1e3 / 20
-            net["line"] = {
-                "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
-                "value": round(2.0 * M * N * K * Ks / sdt / 1e12, 2), "unit": "TOPS", "n_gpus": world, "steps": Ks, "warmup": args.warmup,
-                "ms_per_step": round(sdt / Ks * 1e3, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
-                           "parallelism": f"tp{world}: W column-sharded ({nls} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant",
-                           "launch": "hipgraph x1 step/replay, collective eager behind each step", "collective_in_graph": False, "repeats": 5,
-                           "timed": f"median of 5 blocks of exactly {Ks} steps (barrier + synchronize around each block, max over ranks)", **infos},
-                "ms_per_step_min": round(bl[0] / Ks * 1e3, 5), "ms_per_step_max": round(bl[-1] / Ks * 1e3, 5),
-                "roofline": {"bound": "mfma", "kernel": lib.pq_gemm_variant_name(M, nls, K, K, K).decode(), "achieved": round(2.0 * M * nls * K / tg / 1e6, 1), "peak": PEAK_INT8_TOPS,
-                             "unit": "TOP/s", "frac": round(2.0 * M * nls * K / tg / 1e6 / PEAK_INT8_TOPS, 4), "avg_kernel_us": round(tg, 2),
-                             "how": "one hipGraph replay of 20 back-to-back launches of the rank's shard GEMM, HIP events on the launch stream", "traffic": None},
-                "cpu_baseline": None,
-                "fallback": f"the native exchange (libpq_rccl.so, captured into the step graph) did not produce its line within {args.native_timeout:.0f} s: "
-                            "this is the same step with torch.distributed's all-gather, measured before the native path was tried",
-            }
-            del gs_, gk_, k1s, k3s, gathers, _keeps
-        except Exception as e:      # the net must never cost the run
-            print(f"[bench] safety-net measurement failed ({e}); continuing without it", file=sys.stderr)
-
-        def fire():
-            with net["lock"]:
-                if net["done"]:
-                    return
-                net["done"] = True
-                print(f"[bench] rank {rank}: the native RCCL path did not finish within {args.native_timeout:.0f} s — "
-                      + ("printing the torch.distributed line" if net["line"] else "no safe line either"), file=sys.stderr)
-                if rank == 0 and net["line"] is not None:
-                    emit_json(net["line"])
-                sys.stderr.flush()
-                os._exit(0 if net["line"] is not None else 3)
-        net["timer"] = threading.Timer(args.native_timeout, fire)
-        net["timer"].daemon = True
-        net["timer"].start()
-        if args.simulate_native_hang:
-            while True:
-                time.sleep(1.0)
-
-    k1, k3, gather, n_local, xinfo, _keep = build_step(tp)
-
-    # ---- the step.  Everything is replayed from a hipGraph of S steps (host-independent): K1 + K3/K4 and, in a tp step, the exchange as
-    # well — RCCL collectives are capturable, and a ~60 us step issued collective by collective from Python would time the host, not
-    # xGMI.  Only if that capture fails (or the exchange goes through torch.distributed) is the collective issued eagerly behind each
-    # step's compute graph; the line says which, and carries the host time per step next to the device time either way.
+    # ---- the step: K1 + K3/K4 replayed from a hipGraph of S steps (host-independent)
     K_steps = max(1, args.steps)
-    use_graph = not args.no_graph
     g_main = g_rem = None
-    coll_in_graph = False
-    if tp and use_graph and xinfo.get("native"):
+    S = min(K_steps, 50)
+    if not args.no_graph:
         try:
-            gather(); torch.cuda.synchronize()                 # (allocates the exchange workspace outside the capture)
-            S = min(K_steps, 20)
-            g_main = graph_of(lambda: (k1(), k3(), gather()), S)
+            g_main = graph_of(lambda: (k1(), k3()), S)
             if K_steps % S:
-                g_rem = graph_of(lambda: (k1(), k3(), gather()), K_steps % S)
-            coll_in_graph = True
-        except Exception as e:
-            print(f"[bench] capturing the RCCL exchange into the step graph failed ({e}); collective issued eagerly behind each step", file=sys.stderr)
+                g_rem = graph_of(lambda: (k1(), k3()), K_steps % S)
+        except Exception as e:   # report, never silently change what is measured
+            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
             g_main = g_rem = None
-        if dist is not None:                                   # every rank must replay the same thing
-            ok = torch.tensor([1 if coll_in_graph else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            coll_in_graph = bool(int(ok.item()))
-            if not coll_in_graph:
-                g_main = g_rem = None
-    if not coll_in_graph:
-        S = 1 if tp else min(K_steps, 50)
-        if use_graph:
-            try:
-                g_main = graph_of(lambda: (k1(), k3()), S)
-                if K_steps % S:
-                    g_rem = graph_of(lambda: (k1(), k3()), K_steps % S)
-            except Exception as e:   # report, never silently change what is measured
-                print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
-                g_main = g_rem = None
-    whole_step_in_graph = g_main is not None and (not tp or coll_in_graph)
 
     def run_steps(n):
         """exactly n steps"""
-        if whole_step_in_graph:
+        if g_main is not None:
             for _ in range(n // S):
                 g_main.replay()
             if n % S:
-                fn = (lambda: (k1(), k3(), gather())) if tp else (lambda: (k1(), k3()))
-                (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(fn, n % S)).replay()
+                (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(lambda: (k1(), k3()), n % S)).replay()
             return
         for _ in range(n):
-            if g_main is not None:
-                g_main.replay()
-            else:
-                k1(); k3()
-            if gather is not None:
-                gather()
+            k1(); k3()
 
     # ---- warm-up: the W steps the caller asked for, then warm-up BY TIME (SURVEY §8d: clocks and caches settle under
     # ~2 s of this very load; a fresh box otherwise times its own power ramp) — all untimed
@@ -913,6 +1263,21 @@ def main():
     blocks.sort()
     dt = blocks[len(blocks) // 2]
 
+    # ---- verification of what was just timed (rank-local, outside the timed region): the step's y must be the bits torch's own ops give for QSPEC E1-E4 around
+    # torch._int_mm on THIS GPU, from the step's own codes and scales (the int32 accumulator through hipBLASLt — exact integers, one answer; the epilogue is three
+    # correctly rounded float ops, the same on every IEEE device).  The codes themselves are pinned to the CPU oracle by the -m gpu suite, not here.
+    verified = None
+    try:
+        y.zero_(); run_steps(1); torch.cuda.synchronize()
+        acc = torch._int_mm(xq, wq.t())
+        y_chk = ((acc.float() * xs[:, None]) * ws[None, :]).to(torch.bfloat16)
+        verified = bool(torch.equal(y_chk.view(torch.int16), y.view(torch.int16)))
+        del acc, y_chk
+        if not verified:
+            print("[bench] WARNING: the timed step's output differs from torch._int_mm + E1-E4 on the same codes", file=sys.stderr)
+    except Exception as e:      # a check that cannot run must not lose the line; it is reported as null
+        print(f"[bench] verification leg failed: {e}", file=sys.stderr)
+
     # ---- per-kernel durations, live, on the launch stream: each kernel of the step replayed gap-free from its own hipGraph,
     # on the step's buffers, interleaved with the step graph in the same rounds (same clocks), HIP events around each replay.
     def ev_us(g, n):
@@ -933,7 +1298,6 @@ def main():
     # the same eighth of x every launch, and write-through stores leave nothing dirty to evict it) and the 256-MB Infinity Cache —
     # 6.3-6.6 us, "0.95 of 8 TB/s", a cache figure.  The roofline entry therefore rotates over enough distinct input / output
     # pairs (> 600 MB in total) that every launch reads from and writes to HBM; the cache-resident replay is reported beside it.
-    x_, _xq, _xs, _y, _wq, _ws, _w = _keep
     n_rot = max(2, -(-600 * 2**20 // (3 * M * K)))
     rot = [(torch.randn(M, K, device=dev).to(torch.bfloat16), torch.empty((M, K), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
            for _ in range(n_rot)]
@@ -949,76 +1313,45 @@ def main():
     # the GEMM with its weights streamed from HBM (a layer inside a model reads its weights once per pass): rotation over enough distinct
     # weight matrices that none stays in the Infinity Cache; the activation operand stays the step's (cache-resident, as in a model)
     t_gemm_hbm = t_gemm_hbm_ref = None
-    if not tp:
-        try:
-            n_w = max(2, -(-640 * 2**20 // (N * K)))
-            wrot = [_wq] + [_wq.clone() for _ in range(n_w - 1)]
-            wbytes_ = lib.pq_qlinear_workspace_bytes(M, N, K)
+    try:
+        n_w = max(2, -(-640 * 2**20 // (N * K)))
+        wrot = [wq] + [wq.clone() for _ in range(n_w - 1)]
 
-            def k3_rot():
-                for w_ in wrot:
-                    L.check(lib.pq_qlinear_s8(_xq.data_ptr(), K, _xs.data_ptr(), w_.data_ptr(), K, _ws.data_ptr(), None, _y.data_ptr(), N, 0, M, N, K,
-                                              _w.data_ptr() if wbytes_ else None, wbytes_, st()), "pq_qlinear_s8")
-            g_wr = graph_of(k3_rot, 1)
-            g_wr.replay(); torch.cuda.synchronize()
-            # interleaved with the cache-resident replay, round by round: both figures see the same clocks (measured alone, a 2-ms graph of HBM-fed launches and a
-            # 1-ms graph of warm ones sit at different points of the chip's power management, and the difference reads as an "HBM penalty" that is not one)
-            th, tw_ = [], []
-            for _ in range(9):
-                th.append(ev_us(g_wr, n_w)); tw_.append(ev_us(gk3, PG))
-            t_gemm_hbm, t_gemm_hbm_ref = med(th), med(tw_)
-            del wrot, g_wr
-        except Exception as e:      # an extra figure must never lose the main line
-            print(f"[bench] HBM-fed GEMM leg failed: {e}", file=sys.stderr)
-    # the same K1 kernel on a 4x taller activation (16384 rows; 192 MiB in + out per launch, two rotating inputs): the fixed part of
+        def k3_rot():
+            for w_ in wrot:
+                L.check(lib.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), w_.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K,
+                                          wsp.data_ptr() if wbytes else None, wbytes, st()), "pq_qlinear_s8")
+        g_wr = graph_of(k3_rot, 1)
+        g_wr.replay(); torch.cuda.synchronize()
+        # interleaved with the cache-resident replay, round by round: both figures see the same clocks (measured alone, a 2-ms graph of HBM-fed launches and a
+        # 1-ms graph of warm ones sit at different points of the chip's power management, and the difference reads as an "HBM penalty" that is not one)
+        th, tw_ = [], []
+        for _ in range(9):
+            th.append(ev_us(g_wr, n_w)); tw_.append(ev_us(gk3, PG))
+        t_gemm_hbm, t_gemm_hbm_ref = med(th), med(tw_)
+        del wrot, g_wr
+    except Exception as e:      # an extra figure must never lose the main line
+        print(f"[bench] HBM-fed GEMM leg failed: {e}", file=sys.stderr)
+    # the same K1 kernel on a 4x taller activation (16384 rows; 192 MiB in + out per launch, three rotating inputs): the fixed part of
     # a launch (ramp + tail, ~1.4 us) weighs less
-    k1_big = None
-    if not tp:
-        Mb = 4 * M
-        bigs = [(torch.randn(Mb, K, device=dev).to(torch.bfloat16), torch.empty((Mb, K), dtype=torch.int8, device=dev), torch.empty((Mb,), dtype=torch.float32, device=dev))
-                for _ in range(3)]
+    Mb = 4 * M
+    bigs = [(torch.randn(Mb, K, device=dev).to(torch.bfloat16), torch.empty((Mb, K), dtype=torch.int8, device=dev), torch.empty((Mb,), dtype=torch.float32, device=dev))
+            for _ in range(3)]
 
-        def k1_big_rot():
-            for xb_, qb_, sb_ in bigs:
-                L.check(lib.pq_quant_rowwise(xb_.data_ptr(), 0, Mb, K, K, qb_.data_ptr(), K, sb_.data_ptr(), st()), "pq_quant_rowwise")
-        gb_ = graph_of(k1_big_rot, 3)
-        gb_.replay(); torch.cuda.synchronize()
-        tb = med([ev_us(gb_, 9) for _ in range(15)])
-        k1_big = {"rows": Mb, "cols": K, "avg_kernel_us": round(tb, 2), "achieved": round((3 * Mb * K + 4 * Mb) / tb / 1e3, 1), "unit": "GB/s",
-                  "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4), "how": "three rotating 16384 x 4096 inputs (576 MiB per round): HBM-fed"}
-        del bigs, gb_
-    # tp: the exchange (collective + layout pass) by itself, gap-free from its own graph when it is capturable, else eager launches between
-    # events; every rank runs it in step (a collective), the MAX over ranks is reported
-    t_exch = None
-    if tp and gather is not None:
-        fence()
-        try:
-            if coll_in_graph:
-                g_ex = graph_of(gather, PG)
-                g_ex.replay(); fence()
-                v = med([ev_us(g_ex, PG) for _ in range(9)])
-            else:
-                def ex_eager():
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(PG):
-                        gather()
-                    b.record(); b.synchronize()
-                    return a.elapsed_time(b) * 1e3 / PG
-                ex_eager(); fence()
-                v = med([ex_eager() for _ in range(9)])
-            tt = torch.tensor([v], dtype=torch.float64, device=dev)
-            if dist is not None:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_exch = float(tt.item())
-        except Exception as e:
-            print(f"[bench] exchange-only timing failed: {e}", file=sys.stderr)
-        fence()
+    def k1_big_rot():
+        for xb_, qb_, sb_ in bigs:
+            L.check(lib.pq_quant_rowwise(xb_.data_ptr(), 0, Mb, K, K, qb_.data_ptr(), K, sb_.data_ptr(), st()), "pq_quant_rowwise")
+    gb_ = graph_of(k1_big_rot, 3)
+    gb_.replay(); torch.cuda.synchronize()
+    tb = med([ev_us(gb_, 9) for _ in range(15)])
+    k1_big = {"rows": Mb, "cols": K, "avg_kernel_us": round(tb, 2), "achieved": round((3 * Mb * K + 4 * Mb) / tb / 1e3, 1), "unit": "GB/s",
+              "frac": round((3 * Mb * K + 4 * Mb) / tb / 1e3 / PEAK_HBM_GBS, 4), "how": "three rotating 16384 x 4096 inputs (576 MiB per round): HBM-fed"}
+    del bigs, gb_
     consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)       # cache-hot K1 <= in-step K1 <= HBM-cold K1
     host_us = sorted(host_enq)[len(host_enq) // 2] / K_steps * 1e6
     step_us = dt / K_steps * 1e6
     # a step that is not replayed whole from a graph is only a device measurement while the host enqueues faster than the device runs
-    host_bound = (not whole_step_in_graph) and host_us > 0.9 * step_us
+    host_bound = (g_main is None) and host_us > 0.9 * step_us
     if host_bound:
         print(f"[bench] WARNING: host-bound step: enqueueing takes {host_us:.1f} us per step, the step {step_us:.1f} us — this line times Python, not the device", file=sys.stderr)
         consistent = False
@@ -1029,29 +1362,30 @@ def main():
     else:
         assert consistent or host_bound or args.no_consistency_check or args.share_gpu, msg
 
-    ops_job = 2.0 * M * N * K * (1 if tp else world)       # whole job per step
+    ops_job = 2.0 * M * N * K * world                      # whole job per step
     value = ops_job * K_steps / dt / 1e12
     k1_bytes = 3 * M * K + 4 * M                           # read bf16, write s8 + one f32 per row
-    gemm_bytes = M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local)
-    gemm_ops = 2.0 * M * n_local * K
-    variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
+    gemm_bytes = M * K + N * K + 2 * M * N + 4 * (M + N)
+    gemm_ops = 2.0 * M * N * K
+    variant = lib.pq_gemm_variant_name(M, N, K, K, K).decode()
     kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
              "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
-    if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
+    if wbytes > 0:
         kname += " split-K + splitk_reduce_epilogue"
 
     out = {
         "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
         "value": round(value, 2), "unit": "TOPS", "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
         "ms_per_step": round(dt / K_steps * 1e3, 5), "higher_is_better": True,
-        "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
         "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
-                   "parallelism": (f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant"
-                                   if tp else f"dp{world} over tokens, replicated int8 weights, no collective"),
-                   "launch": (f"hipgraph x{S} steps/replay" + ((", RCCL exchange captured in the graph" if coll_in_graph else ", collective eager behind each step") if tp else "") if g_main is not None else "eager"),
-                   "collective_in_graph": (coll_in_graph if tp else None),
+                   "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective",
+                   "launch": f"hipgraph x{S} steps/replay" if g_main is not None else "eager",
+                   "collective_in_graph": None,
                    "repeats": R, "timed": f"median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks)",
-                   "warmup_seconds": args.warmup_seconds, "gemm_variant": variant, **xinfo},
+                   "warmup_seconds": args.warmup_seconds, "gemm_variant": variant},
+        "verified": verified,
+        "verified_how": "after the timed blocks: y of one more step == torch._int_mm (hipBLASLt) on the step's own codes + E1-E4 in torch ops on this GPU, bit for bit",
         "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(gemm_ops / t_gemm / 1e6, 1),
                      "peak": PEAK_INT8_TOPS, "unit": "TOP/s", "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4),
@@ -1069,108 +1403,30 @@ def main():
         "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
         "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool(host_bound),
     }
-    if tp:
-        # compute and exchange of the tp step, separately (per rank; device time): K1 (replicated) + the local GEMM, and the all-gather
-        # + layout pass.  compute_us + exchange_us ~ the step: the exchange is not overlapped in this form.
-        out["compute_us"] = round(t_stepc, 2)
-        out["exchange_us"] = round(t_exch, 2) if t_exch is not None else None
-        out["exchange_bytes_received_per_rank"] = 2 * M * (N - n_local)
-        # DESIGN.md §6's model of this very step for this G, so that measured-vs-modelled is one subtraction: the rank's MEASURED compute, the
-        # all-gather at the point-to-point link rate (every peer's shard arrives over its own xGMI link, ~153 GB/s each, all links busy at
-        # once), and the layout pass that interleaves the stacked shards into y[M, N] (reads + writes 2 M N bytes at ~5 TB/s)
-        XGMI_LINK_GBS, LAYOUT_TBS = 153.0, 5.0
-        shard_bytes = 2 * M * n_local
-        m_ag = shard_bytes / (XGMI_LINK_GBS * 1e3) if world > 1 else 2 * M * N / (LAYOUT_TBS * 1e6)     # world 1: a device-local copy
-        m_lay = 2 * (2 * M * N) / (LAYOUT_TBS * 1e6)
-        out["modelled"] = {"compute_us": round(t_stepc, 2), "allgather_us": round(m_ag, 2), "layout_pass_us": round(m_lay, 2),
-                           "step_us": round(t_stepc + m_ag + m_lay, 2),
-                           "assumptions": f"per-rank shard {shard_bytes} B over one direct xGMI link per peer at {XGMI_LINK_GBS:.0f} GB/s, all {max(world - 1, 1)} links concurrently; "
-                                          f"layout pass at {LAYOUT_TBS:.0f} TB/s; no overlap of exchange and compute (DESIGN.md §6)"}
-        out["config"]["modelled_step_us"] = out["modelled"]["step_us"]
-        out["measured_minus_modelled_us"] = round(step_us - out["modelled"]["step_us"], 2)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         try:
             tr = json.load(open(tj))
-            if (M, n_local, K) == (4096, 4096, 4096):
+            if (M, N, K) == (4096, 4096, 4096):
                 out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = tr.get("source")
-            else:       # tp: the rank's shard GEMM is another shape: PMC passes per shard width, where collected
+            else:
                 by = tr.get("gemm_hbm_bytes_per_launch_by_shape", {})
-                out["roofline"]["traffic"] = by.get(f"{M}x{n_local}x{K}")
+                out["roofline"]["traffic"] = by.get(f"{M}x{N}x{K}")
                 out["roofline"]["traffic_source"] = tr.get("source_by_shape") if out["roofline"]["traffic"] else None
         except Exception:
             pass
-    if tp and args.tp_transposed_leg and xinfo.get("exchange", "").startswith("libpq_rccl"):
-        # extra key: the same split with TRANSPOSED shards (pq_qlinear_s8_t -> y^T[n0:n1, :], one contiguous all-gather into
-        # y^T[N, M], no staging buffer and no layout kernel; the result is y as a column-major view with the same bits)
-        try:
-            from protoquant_amd.sharded import RcclColumnGather as _RG
-            rg_t = _RG()
-            x_, xq_, xs_, y_, wq_, ws_, _w = _keep
-            yt_loc = torch.empty((n_local, M), dtype=torch.bfloat16, device=dev)
-            yt_full = torch.empty((N, M), dtype=torch.bfloat16, device=dev)
-            wb_t = lib.pq_qlinear_t_workspace_bytes(M, n_local, K)
-            wsp_t = torch.empty((max(wb_t, 16),), dtype=torch.uint8, device=dev)
-
-            def k3t():
-                L.check(lib.pq_qlinear_s8_t(xq_.data_ptr(), K, xs_.data_ptr(), wq_.data_ptr(), K, ws_.data_ptr(), None, yt_loc.data_ptr(), M, 0,
-                                            M, n_local, K, wsp_t.data_ptr() if wb_t else None, wb_t, st()), "pq_qlinear_s8_t")
-            gt = graph_of(lambda: (k1(), k3t()), 1)
-            for _ in range(10):
-                gt.replay(); rg_t.gather_t(yt_loc, N, out=yt_full)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(200):
-                gt.replay(); rg_t.gather_t(yt_loc, N, out=yt_full)
-            torch.cuda.synchronize()
-            d = time.perf_counter() - t0
-            tt = torch.tensor([d], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            out["tp_transposed"] = {"value": round(2.0 * M * N * K * 200 / float(tt.item()) / 1e12, 2), "unit": "TOPS", "ms_per_step": round(float(tt.item()) / 200 * 1e3, 5),
-                                    "exchange": "pq_qlinear_s8_t + pq_allgather_rows_t (contiguous ncclAllGather, no layout kernel); y returned as the column-major view y^T.t()"}
-            rg_t.close()
-        except Exception as e:      # an extra figure must never lose the main line
-            print(f"[bench] transposed-shard leg failed: {e}", file=sys.stderr)
-    if tp and not args.no_dp_leg:
-        # extra key: the same ranks as independent replicas over tokens (weak scaling, no collective), short
-        k1d, k3d, _g, _nl, _i, _keep2 = build_step(False)
-        gd = graph_of(lambda: (k1d(), k3d()), PG)
-        for _ in range(10):
-            gd.replay()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(25):
-            gd.replay()
-        torch.cuda.synchronize()
-        d = time.perf_counter() - t0
-        tt = torch.tensor([d], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        out["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / float(tt.item()) / 1e12, 2), "unit": "TOPS", "scaling": "weak",
-                     "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
     if world == 1 and not args.no_gpu_context:
-        x_, _xq, _xs, y_, wq_, ws_, _w = _keep
         k1(); k3(); torch.cuda.synchronize()
-        out["gpu_context"] = gpu_context(x_, wq_, ws_, y_, med)
+        out["gpu_context"] = gpu_context(x, wq, ws, y, med)
         t_pipe = out["gpu_context"].get("torch_rocm_int8_pipeline_us")
         if t_pipe:
             out["gpu_context"]["library_step_us"] = round(t_stepc, 2)
             out["gpu_context"]["speedup_vs_torch_rocm_int8_pipeline"] = round(t_pipe / t_stepc, 2)
             out["gpu_context"]["speedup_vs_torch_bf16_linear"] = round(out["gpu_context"]["torch_bf16_linear_us"] / t_stepc, 2)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(M, N, K)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    with net["lock"]:
-        if net["done"]:            # the watchdog has spoken for this rank (it is about to end the process)
-            return
-        net["done"] = True
-        if net["timer"] is not None:
-            net["timer"].cancel()
-        if rank == 0:
-            if net["line"] is not None:
-                out["torch_distributed_exchange_ms_per_step"] = net["line"]["ms_per_step"]       # the safety net's figure, beside the native one
-            emit_json(out)
+    if rank == 0:
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(M, N, K)     # rank 0, after every timed region, at every world size
+        emit_json(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,6 +24,7 @@ def test_headline_json_contract():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["verified"] is True            # the timed step's y == torch._int_mm on its own codes + E1-E4 in torch ops, bit for bit
     assert d["unit"] == "TOPS" and d["dtype"] == "s8" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 2.0 * 4096**3 / (d["ms_per_step"] * 1e-3) / 1e12) < 0.02 * d["value"]
@@ -53,7 +54,9 @@ def test_headline_json_contract():
 
 def test_tp_dry_run_two_ranks_one_gpu():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU over gloo: the N > 1 line is
-    north_star's split (column-sharded weight + all-gather, strong scaling) with the dp figure as an extra key."""
+    north_star's split (column-sharded weight + all-gather, strong scaling) with the dp figure as an extra key; every exchange form that can
+    run here (the torch.distributed ones: RCCL refuses two ranks on one GPU) is a timed, VERIFIED leg, and the line carries cpu_baseline and a
+    model per leg at this world size too."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "3",
                         "--warmup-seconds", "0.2", "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600)
@@ -62,7 +65,16 @@ def test_tp_dry_run_two_ranks_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"].startswith("tp2") and d["config"]["rccl_ranks"] == 2
-    assert d["dp"]["scaling"] == "weak" and d["dp"]["value"] > 0 and d["cpu_baseline"] is None
+    assert d["dp"]["scaling"] == "weak" and d["dp"]["value"] > 0
+    assert set(d["legs"]) == {"torch_plain", "torch_transposed"} and d["native_exchange"] == "not_attempted"
+    for name, leg in d["legs"].items():
+        assert leg["verified"] is True and leg["value"] > 0 and leg["modelled"]["step_us"] > 0 and leg["exchange_us"] > 0, (name, leg)
+    assert d["verified"] is True and d["config"]["headline_leg"] in d["legs"]
+    assert d["ms_per_step"] == min(l["ms_per_step"] for l in d["legs"].values())         # the headline is the fastest verified leg
+    assert abs(d["value"] - 2.0 * 4096**3 / (d["ms_per_step"] * 1e-3) / 1e12) < 0.02 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert d["roofline"]["traffic"] and d["roofline"]["frac"] > 0.1 and "4096x2048x4096" in d["roofline"]["how"]
 
 
 def test_plain_invocation_launches_its_own_ranks():
@@ -70,13 +82,13 @@ def test_plain_invocation_launches_its_own_ranks():
     itself (children, before any GPU call) and relays rank 0's single JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "3",
-                        "--warmup-seconds", "0.2", "--backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=600, env=env)
+                        "--warmup-seconds", "0.2", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["scaling"] == "strong"
-    assert "modelled_step_us" in d["config"] and d["config"]["modelled_step_us"] > 0
+    assert "modelled_step_us" in d["config"] and d["config"]["modelled_step_us"] > 0 and d["verified"] is True
 
 
 def test_plain_invocation_reports_a_failed_launch():

@@ -62,21 +62,33 @@ def test_overlapped_exchange_under_graph_capture_world1(pq):
             dist.destroy_process_group()
 
 
+NATIVE_LEGS = {"native_plain", "native_transposed", "native_overlap2", "native_overlap4", "native_overlap8"}
+
+
 def test_bench_tp_step_is_one_graph_world1():
-    """bench.py --mode tp on ONE GPU (a 1-rank RCCL communicator): the step the driver times at N > 1 — K1, the shard GEMM, the RCCL
-    all-gather and the layout pass — is replayed whole from a hipGraph, and the line carries compute and exchange separately."""
+    """bench.py --mode tp on ONE GPU (a 1-rank RCCL communicator): the step the driver times at N > 1.  Every exchange form the repo holds is a leg — the plain
+    gather + layout pass, transposed shards (no layout pass), 2 / 4 / 8 row blocks overlapped on the communicator's side stream — each replayed whole from a
+    hipGraph (K1, the shard GEMMs and the RCCL collectives captured), each verified bit for bit against the unsharded qlinear; the headline is the fastest
+    verified leg and carries compute and exchange separately."""
     env = dict(os.environ, MASTER_PORT="29563", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3",
-                        "--warmup-seconds", "0.3", "--no-cpu-baseline", "--no-gpu-context", "--no-dp-leg"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup-seconds", "0.3", "--no-cpu-baseline", "--no-dp-leg"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])       # (RCCL prints its version banner to stdout as well)
-    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["collective_in_graph"] is True, line["config"]
-    assert line["config"]["rccl_ranks"] == 1 and "captured in the graph" in line["config"]["launch"]
-    assert line["host_bound"] is False and line["exchange_us"] > 0 and line["compute_us"] > 0
-    assert line["ms_per_step"] * 1e3 >= 0.9 * line["compute_us"]                 # the exchange is in the step
-    assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["native_exchange"] == "ok" and line["config"]["rccl_ranks"] == 1
+    legs = line["legs"]
+    assert set(legs) == NATIVE_LEGS | {"torch_plain", "torch_transposed"}, sorted(legs)
+    for name, leg in legs.items():
+        assert leg["verified"] is True and leg["value"] > 0 and leg["exchange_us"] > 0 and leg["compute_us"] > 0 and leg["modelled"]["step_us"] > 0, (name, leg)
+        if name in NATIVE_LEGS:
+            assert leg["collective_in_graph"] is True and "captured in the graph" in leg["launch"] and leg["host_bound"] is False, (name, leg)
+            assert leg["ms_per_step"] * 1e3 >= 0.9 * leg["compute_us"]           # the exchange is in the step
+    head = line["config"]["headline_leg"]
+    assert line["verified"] is True and line["ms_per_step"] == min(l["ms_per_step"] for l in legs.values()) == legs[head]["ms_per_step"]
+    assert line["exchange_us"] > 0 and line["compute_us"] > 0 and line["config"]["exchange"] == legs[head]["exchange"]
+    assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True and line["cpu_baseline"] is None
 
 
 def _bench_tp(extra, port):
@@ -84,30 +96,32 @@ def _bench_tp(extra, port):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3", "--warmup-seconds", "0.3",
-                        "--no-cpu-baseline", "--no-gpu-context", "--no-dp-leg", "--safety-net", *extra], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-dp-leg", *extra], env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, lines
 
 
-def test_bench_tp_safety_net_prints_the_torch_distributed_line_when_the_native_path_hangs():
-    """A multi-GPU run must never be lost to a hung collective: before the native exchange (a second RCCL communicator, captured into the step graph) is tried,
-    bench.py measures the same step with torch.distributed's all-gather; if the native path does not produce its line in time, a watchdog prints that one and the
-    rank exits 0.  Here the hang is simulated (the native phase never returns)."""
+def test_bench_tp_watchdog_prints_the_best_finished_leg_when_a_native_leg_hangs():
+    """A multi-GPU run must never be lost to a hung collective: the torch.distributed legs are measured (and verified) before the native exchange (a second RCCL
+    communicator) is touched, and every native leg runs under its own watchdog; when one does not finish in time, rank 0 prints the fastest VERIFIED leg among
+    those that finished, marked "native_exchange": "hung", and the rank exits 0.  Here the hang is simulated (the native phase never returns)."""
     r, lines = _bench_tp(["--simulate-native-hang", "--native-timeout", "8"], "29565")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert "fallback" in line and line["config"]["collective_in_graph"] is False and line["config"]["exchange"].startswith("torch.distributed")
+    assert line["native_exchange"] == "hung" and "fallback" in line and line["hung_leg"] == "communicator bootstrap"
+    assert set(line["legs"]) == {"torch_plain", "torch_transposed"} and line["config"]["headline_leg"] in line["legs"]
+    assert line["config"]["collective_in_graph"] is False and "torch.distributed" in line["config"]["exchange"] and line["verified"] is True
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["value"] > 0 and line["scaling"] == "strong" and line["roofline"]["frac"] > 0.2
     assert "did not finish" in r.stderr
 
 
-def test_bench_tp_safety_net_stays_silent_when_the_native_path_finishes():
+def test_bench_tp_line_says_native_ok_when_every_leg_finishes():
     r, lines = _bench_tp([], "29566")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert "fallback" not in line and line["config"]["collective_in_graph"] is True
-    assert line["torch_distributed_exchange_ms_per_step"] > 0
+    assert "fallback" not in line and "hung_leg" not in line and line["native_exchange"] == "ok"
+    assert line["torch_distributed_exchange_ms_per_step"] > 0 and NATIVE_LEGS <= set(line["legs"])
