@@ -19,7 +19,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch_ref as R  # noqa: E402
-from tests.synth import FULLSIZE_CASES, fullsize_inputs, sha  # noqa: E402
+from tests.synth import FULLSIZE_CASES, bell_bf16, fullsize_inputs, sha  # noqa: E402
 
 
 def bf(a):
@@ -46,6 +46,27 @@ def main():
                                   xq=sha(bits(xq)), xs=sha(bits(xs)), wq=sha(bits(wq)), ws=sha(bits(ws)), acc=sha(bits(acc)), y=sha(bits(y)),
                                   acc_min=int(acc.min()), acc_max=int(acc.max()))
         print(f"{name}: acc[{int(acc.min())},{int(acc.max())}] {time.time() - t0:.1f}s", flush=True)
+    # BASELINE configs[2] as ONE chain, every stage by torch's own eager ops around torch._int_mm: x -> gate, up (two qlinears on the same activation) ->
+    # F.silu(gate) * up -> per-token quantisation -> down.  For bf16 the eager silu*mul IS QSPEC S1-S5 (exhaustive test in tests/test_oracle.py), so the
+    # digests pin the producer-fused kernel (K1s) and the whole GatedMLP block to torch-generated data at full size.
+    t0 = time.time()
+    x, wg, _ = fullsize_inputs("cfg3_gate_2048x11008x4096")
+    _, wu, _ = fullsize_inputs("cfg3_up_2048x11008x4096")
+    _, wd, _ = fullsize_inputs("cfg3_down_2048x4096x11008")
+    (gq, gs), (uq, us), (dq, ds) = (R.quantize_ref(bf(w_), 1) for w_ in (wg, wu, wd))
+    gate, xq, xs, _ = R.qlinear_ref(bf(x), gq, gs)
+    up = R.qlinear_ref(bf(x), uq, us)[0]
+    hq, hs, h = R.silu_mul_quantize_ref(gate, up)
+    y = R.epilogue_ref(R.int_gemm_ref(hq, dq), hs, ds, None, torch.bfloat16)
+    out["chains"] = {"cfg3_mlp_block_2048x4096x11008": dict(
+        what="x[2048,4096] -> gate/up (W 11008x4096 each) -> F.silu(gate)*up -> quantize -> down (W 4096x11008); inputs: the x of cfg3_gate and the weights of the three cfg3 cases, no bias",
+        x=sha(x), gate=sha(bits(gate)), up=sha(bits(up)), h=sha(bits(h)), hq=sha(bits(hq)), hs=sha(bits(hs)), y=sha(bits(y)))}
+    # the producer alone on inputs with a wider spread than GEMM outputs have (|g|, |u| up to 4.0 * 4: both tails of the sigmoid)
+    g_in, u_in = bell_bf16(2048, 11008, 41, -13), bell_bf16(2048, 11008, 42, -15)
+    hq2, hs2, h2 = R.silu_mul_quantize_ref(bf(g_in), bf(u_in))
+    out["chains"]["silu_mul_quant_2048x11008"] = dict(what="quantize(F.silu(g) * u), g = bell_bf16(seed 41, 2^-13), u = bell_bf16(seed 42, 2^-15)",
+                                                      g=sha(g_in), u=sha(u_in), h=sha(bits(h2)), hq=sha(bits(hq2)), hs=sha(bits(hs2)))
+    print(f"chains: {time.time() - t0:.1f}s", flush=True)
     with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")

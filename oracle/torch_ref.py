@@ -65,3 +65,30 @@ def qlinear_ref(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None):
     acc = int_gemm_ref(xq, wq)
     y = epilogue_ref(acc, xs, ws, bias, x.dtype)
     return y, xq, xs, acc
+
+
+def silu_mul_ref(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """The eager producer of the gated MLP as a model writes it: ``F.silu(g) * u`` (two ops, two storage roundings).
+    For bf16 / fp16 tensors this IS QSPEC S1-S5, bit for bit, on every input: S1-S5's silu equals torch's CPU ``F.silu`` on all
+    65 536 patterns of either 16-bit type (tests/test_oracle.py::test_silu_spec_is_torch_eager_on_every_16bit_pattern), and the
+    product of two 16-bit floats is exact in binary32, so ``* u`` is one deterministic rounding in both.  For fp32 tensors torch's
+    own exp carries its ulp and the stored h may differ in the last bits (bounded in tests/test_oracle.py); fp32 activations are
+    outside BASELINE.json's configurations."""
+    return torch.nn.functional.silu(g) * u
+
+
+def silu_mul_quantize_ref(g: torch.Tensor, u: torch.Tensor):
+    """quantize(F.silu(g) * u) per token: the torch form of QSPEC S1-S6 for 16-bit activations.  Returns (codes, scales, h)."""
+    h = silu_mul_ref(g, u)
+    q, s = quantize_ref(h, 1)
+    return q, s, h
+
+
+def rmsnorm_eager_ref(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """HF ``LlamaRMSNorm.forward``, op for op (the eager chain a swapped model would otherwise run before its q/k/v and gate/up
+    linears).  NOT the spec: QSPEC N1-N6 pins one summation order for the mean of squares, torch's ``mean`` has its own, so the
+    stored activation can differ in the last bit on a small share of elements — measured by oracle/measure_rmsnorm_vs_eager.py
+    (profiles/r05_rmsnorm_vs_eager.txt) and bounded in tests/test_oracle.py."""
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    return weight * (xf * torch.rsqrt(var + eps)).to(x.dtype)

@@ -15,7 +15,8 @@ from tests.synth import FULLSIZE_CASES, bell_bf16, fullsize_inputs, sha
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(ROOT, "tests", "golden", "fullsize_hashes.json")) as _f:
-    HASHES = json.load(_f)["cases"]
+    _ALL = json.load(_f)
+HASHES, CHAINS = _ALL["cases"], _ALL["chains"]
 
 
 def test_fixture_covers_every_case():
@@ -51,6 +52,59 @@ def test_c_and_numpy_oracles_reproduce_torch_digests_at_4096_cubed():
     acc = Q.gemm_s8s8s32(xq, wq)
     assert sha(acc) == h["acc"]
     assert sha(Q.epilogue(acc, xs, ws, None, 0)) == h["y"]
+
+
+def test_c_oracle_silu_mul_reproduces_torch_eager_digests_at_cfg3_size():
+    """QSPEC S1-S6 in plain C == torch's eager quantize(F.silu(g) * u) (oracle/torch_ref.py::silu_mul_quantize_ref, committed digests) on every bit of the stored
+    product, the codes and the scales of a whole 2048 x 11008 bf16 intermediate — the producer-fused quantisation is pinned to torch-generated data at full size."""
+    from oracle import c_oracle as C
+    h = CHAINS["silu_mul_quant_2048x11008"]
+    g, u = bell_bf16(2048, 11008, 41, -13), bell_bf16(2048, 11008, 42, -15)
+    assert sha(g) == h["g"] and sha(u) == h["u"], "tests/synth.py drifted from the committed digests"
+    q, s, hh = C.silu_mul_quant_rowwise(g, u, 0)
+    assert (sha(hh), sha(q), sha(s)) == (h["h"], h["hq"], h["hs"])
+
+
+@pytest.mark.gpu
+def test_hip_silu_mul_quant_reproduces_torch_eager_digests():
+    """K1s (pq_silu_mul_quant_rowwise) on the GPU == torch's eager quantize(F.silu(g) * u) on the CPU: whole-output digests of codes and scales."""
+    import protoquant_amd as pq
+    from tests.gpu_util import bits, to_gpu
+    h = CHAINS["silu_mul_quant_2048x11008"]
+    g, u = bell_bf16(2048, 11008, 41, -13), bell_bf16(2048, 11008, 42, -15)
+    assert sha(g) == h["g"] and sha(u) == h["u"], "input generator drifted"
+    hq = pq.silu_mul_quantize(to_gpu(g, 0), to_gpu(u, 0))
+    assert sha(bits(hq.int_data)) == h["hq"] and sha(bits(hq.scale)) == h["hs"]
+
+
+@pytest.mark.gpu
+def test_hip_gated_mlp_reproduces_torch_eager_chain_digests():
+    """BASELINE configs[2] end to end against torch-generated data: GatedMLP (fused gate+up GEMM -> K1s -> down) on the GPU reproduces the digests of gate, up,
+    the int8 codes / scales of the intermediate and the block output that torch's own eager ops around torch._int_mm produce on the CPU
+    (oracle/gen_fullsize_hashes.py: qlinear_ref x 2 -> F.silu(gate) * up -> quantize_ref -> torch._int_mm -> epilogue)."""
+    import torch
+
+    import protoquant_amd as pq
+    from tests.gpu_util import bits, to_gpu
+    h = CHAINS["cfg3_mlp_block_2048x4096x11008"]
+    x, wg, _ = fullsize_inputs("cfg3_gate_2048x11008x4096")
+    _, wu, _ = fullsize_inputs("cfg3_up_2048x11008x4096")
+    _, wd, _ = fullsize_inputs("cfg3_down_2048x4096x11008")
+    assert sha(x) == h["x"], "input generator drifted"
+    lins = []
+    for w in (wg, wu, wd):
+        lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device="cuda", dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(to_gpu(w, 0))
+        lins.append(lin)
+    mlp = pq.GatedMLP.from_linears(*lins)
+    xg = to_gpu(x, 0)
+    gate, up = mlp.gate_up(xg)
+    assert sha(bits(gate.contiguous())) == h["gate"] and sha(bits(up.contiguous())) == h["up"], "gate / up"
+    hq = pq.silu_mul_quantize(gate, up)
+    assert sha(bits(hq.int_data)) == h["hq"] and sha(bits(hq.scale)) == h["hs"], "K1s codes / scales"
+    assert sha(bits(mlp.down(hq))) == h["y"], "down on the fused codes"
+    assert sha(bits(mlp(xg))) == h["y"], "GatedMLP.forward"
 
 
 @pytest.mark.gpu
