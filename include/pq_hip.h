@@ -80,6 +80,19 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
                                   int64_t rows, int64_t cols, int8_t* q, int64_t ld_q, float* scale,
                                   void* h_out, int64_t ld_h, void* stream);
 
+/* The two halves of pq_silu_mul_quant_rowwise for an intermediate whose COLUMNS are sharded over ranks (BASELINE config 5, gate/up and down both
+ * column-sharded): a rank holds g, u[rows, cols_local].  The row amax of h = silu(g)*u is an exact max, so
+ *   pq_silu_mul_rowamax            -> amax_bits[rows]: the f32 bit pattern of max |h| over the LOCAL columns (non-negative floats and NaNs order as
+ *                                     unsigned integers: a NaN propagates, as Q2 says);
+ *   all-reduce(max) of amax_bits as uint32 over the ranks (pq_allreduce_max_u32 in pq_rccl.h, or any other exact max);
+ *   pq_silu_mul_quant_rowwise_amax -> q[rows, cols_local] and scale[rows] against the GLOBAL amax (h is recomputed: S1-S5 are deterministic)
+ * give every rank the column block of the unsharded kernel's codes and the unsharded scale vector, bit for bit; the int8 blocks (1 byte per
+ * element instead of 2 x 2 bytes of bf16 g and u) are what travels.  Same numerics, layouts and argument meaning as pq_silu_mul_quant_rowwise. */
+int32_t pq_silu_mul_rowamax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
+                            uint32_t* amax_bits, void* stream);
+int32_t pq_silu_mul_quant_rowwise_amax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
+                                       const uint32_t* amax_bits, int8_t* q, int64_t ld_q, float* scale, void* stream);
+
 /* K1 fused into RMSNorm: quantize(weight * (x.float() * rsqrt(mean(x.float()^2) + eps)).to(dtype)) per
  * token in one pass — the input of the q/k/v and gate/up projections of a decoder layer.  x: [rows, cols], weight: [cols],
  * both of `dtype`; h_out (nullable, ld_h): also store the normalised activation.  Numerics: QSPEC N1-N6 — the sum of squares
@@ -138,6 +151,16 @@ size_t pq_qlinear_t_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, const int8_t* b, int64_t ldb,
                         const float* b_scale, const void* bias, void* yt, int64_t ldyt, int32_t out_dtype, int64_t M,
                         int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
+/* pq_qlinear_s8 on STACKED activation codes: K-slab s — the columns [s * k_per_slab, (s + 1) * k_per_slab) of the logical a[M, K] — is the row-major
+ * block a + s * slab_stride with leading dimension lda (what an all-gather of the ranks' int8 column blocks [M, K / G] leaves: slab_stride = M * K / G).
+ * An integer sum has no order: the result is pq_qlinear_s8's on the row-major matrix, bit for bit.  Where the planner picks the 128 x 128 ring tile (the
+ * Llama-70B `down` shard 4096 x 1024 x 28672 does) its loaders walk the slabs in place — no layout pass, no workspace; any other shape takes ONE layout pass
+ * into `workspace` (M * K bytes read and written) and then pq_qlinear_s8.  K % k_per_slab == 0; workspace per pq_qlinear_kslabs_workspace_bytes (256-byte aligned). */
+size_t pq_qlinear_kslabs_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t k_per_slab);
+int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const float* a_scale, const int8_t* b, int64_t ldb,
+                             const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M, int64_t N, int64_t K,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* qlinear.forward in ONE call: y[M,N] = qlinear(x[M,K]) with dynamic per-token quantisation of x (K1), the int8 MFMA GEMM
  * and the fused dequant epilogue, output dtype = input dtype.  Scratch (xq, xs, optional split-K slabs) is carved from

@@ -56,6 +56,12 @@ int32_t pq_comm_join(void* comm, void* compute_stream);
  * row blocks are contiguous, so ONE ncclAllGather (equal shards) or one group of ncclBroadcasts (ragged) builds
  * yT_full[n_total, M] in place — no staging, no layout kernel. */
 int32_t pq_allgather_rows_t(void* comm, const void* yt_shard, void* yt_full, int64_t n_total, int64_t M, int32_t dtype, void* stream);
+/* The int8-code exchange of the column-sharded gated MLP (BASELINE config 5, gate/up -> down; pq_hip.h: pq_silu_mul_rowamax / pq_silu_mul_quant_rowwise_amax /
+ * pq_qlinear_s8_kslabs): an exact MAX of the ranks' row-amax bit patterns, in place (ncclAllReduce, ncclUint32, ncclMax — non-negative floats and NaNs order as
+ * unsigned integers), and a plain contiguous all-gather of `bytes` bytes per rank into stacked[nranks][bytes] (the ranks' int8 code blocks [M, I / G]; the
+ * consumer walks the stacked blocks in place, so there is no layout pass and no staging buffer). */
+int32_t pq_allreduce_max_u32(void* comm, uint32_t* buf, int64_t count, void* stream);
+int32_t pq_allgather_bytes(void* comm, const void* shard, void* stacked, int64_t bytes, void* stream);
 /* ranks of the communicator as RCCL reports them (ncclCommCount) */
 int32_t pq_comm_count(void* comm, int32_t* nranks);
 

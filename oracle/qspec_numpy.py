@@ -72,6 +72,29 @@ def quantize(x: np.ndarray, dtype, reduce_axis: int):
     return q, scale
 
 
+def row_amax_bits(x: np.ndarray, dtype) -> np.ndarray:
+    """Q2 per token as f32 BIT PATTERNS (uint32 [rows]): non-negative floats and NaNs (above +Inf) order as unsigned integers, so an integer max of these
+    over column blocks is the exact, NaN-propagating row amax — what the column-sharded gated MLP all-reduces (pq_silu_mul_rowamax)."""
+    xf = to_f32(x, dtype)
+    if xf.shape[1] == 0:
+        return np.zeros(xf.shape[0], np.uint32)
+    return (np.abs(xf).view(np.uint32) & np.uint32(0x7FFFFFFF)).max(axis=1).astype(np.uint32)
+
+
+def quantize_rows_with_amax(x: np.ndarray, dtype, amax_bits: np.ndarray):
+    """Q3-Q6 per token against a GIVEN row amax (f32 bit patterns): the column block of quantize(x_full, 1) when amax_bits is the max over all blocks."""
+    xf = to_f32(x, dtype)
+    amax = np.asarray(amax_bits, np.uint32).view(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        scale = (amax / np.float32(127.0)).astype(np.float32)
+        scale = np.where(amax == 0, np.float32(1.0), scale).astype(np.float32)
+        scale = np.where(np.isnan(scale), _CANON_NAN, scale).astype(np.float32)
+        t = np.rint((xf / scale[:, None]).astype(np.float32))
+        t = np.where(np.isnan(t), np.float32(0), t)
+        q = np.clip(t, -128.0, 127.0).astype(np.int8)
+    return q, scale
+
+
 def dequantize(q: np.ndarray, scale: np.ndarray, reduce_axis: int, out_dtype):
     with np.errstate(invalid="ignore", over="ignore"):
         t = q.astype(np.float32) * np.expand_dims(scale.astype(np.float32), reduce_axis)

@@ -16,7 +16,8 @@ UNIQUE_ID_BYTES = 128
 EXPORTS = ("pq_rccl_last_error", "pq_comm_unique_id", "pq_comm_init_rank", "pq_comm_destroy",
            "pq_allgather_cols_workspace_bytes", "pq_allgather_cols", "pq_unstack_cols",
            "pq_reduce_scatter_rows_workspace_bytes", "pq_reduce_scatter_rows", "pq_allgather_cols_v_workspace_bytes",
-           "pq_allgather_cols_v", "pq_allgather_cols_rows_async", "pq_comm_join", "pq_allgather_rows_t", "pq_comm_count", "pq_unstack_cols_v")
+           "pq_allgather_cols_v", "pq_allgather_cols_rows_async", "pq_comm_join", "pq_allgather_rows_t", "pq_comm_count", "pq_unstack_cols_v",
+           "pq_allreduce_max_u32", "pq_allgather_bytes")
 _lib = None
 i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 
@@ -57,6 +58,10 @@ def lib() -> ctypes.CDLL:
     L.pq_allgather_rows_t.argtypes = [vp, vp, vp, i64, i64, i32, vp]
     L.pq_unstack_cols_v.restype = i32
     L.pq_unstack_cols_v.argtypes = [vp, vp, i64, i32, i64, i64, i32, vp]
+    L.pq_allreduce_max_u32.restype = i32
+    L.pq_allreduce_max_u32.argtypes = [vp, vp, i64, vp]
+    L.pq_allgather_bytes.restype = i32
+    L.pq_allgather_bytes.argtypes = [vp, vp, vp, i64, vp]
     L.pq_comm_count.restype = i32
     L.pq_comm_count.argtypes = [vp, ctypes.POINTER(i32)]
     _lib = L

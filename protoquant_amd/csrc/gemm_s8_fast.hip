@@ -1094,7 +1094,7 @@ constexpr int R_TILE = 128, R_NBUF = 4, R_OPER = 128 * FBK /* 16 KiB */, R_BUF =
 template <int OUT, bool LC = false, int ABL = 0>   // ABL (dev builds, timing only): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs, 8 no barriers in the loop, 16 stamps around the consumers' K-loop
 __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W,
                                                        int64_t ldw, EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div,
-                                                       unsigned long long* stamps) {
+                                                       unsigned long long* stamps, KSlabs xs = KSlabs{}) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[R_LDS];
     auto stamp = [&](int point) {     // dev builds (ABL & 16): consumer waves stamp {100 MHz counter, shader cycles} around their K-loop
         if constexpr ((ABL & 16) != 0) {
@@ -1143,8 +1143,17 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     const int8_t* const gP0 = W + (int64_t)n0 * ldw;
     const int8_t* const gQ0 = X + (int64_t)m0 * ldx;
     // (the walk's offset goes through readfirstlane: the rotation's division is vector code, and the DMA's base operand must be provably wave-uniform)
-    const int8_t* gP = gP0 + __builtin_amdgcn_readfirstlane(cpos * FBK);
-    const int8_t* gQ = gQ0 + __builtin_amdgcn_readfirstlane(cpos * FBK);
+    // K-SLAB form of the X operand (pq_qlinear_s8_kslabs; LC form only): the activation codes arrive STACKED as an all-gather leaves them, [G][M][K / G] — K-tile kt lives in
+    // slab kt / xs.tiles at xs.stride bytes per slab, ldx = the slab's row length.  An integer sum has no order, so walking the slabs in place is the row-major GEMM's bits
+    // without the layout pass.  kt / tiles by a host-computed reciprocal (exact for kt < 2^16), all scalar.
+    auto x_off = [&](int ktu) -> int64_t {
+        if (xs.tiles <= 0) return (int64_t)ktu * FBK;
+        const int sl = (int)(((uint64_t)(uint32_t)ktu * (uint64_t)xs.magic) >> 32);
+        return (int64_t)sl * xs.stride + (int64_t)(ktu - sl * xs.tiles) * FBK;
+    };
+    const int kt0u = __builtin_amdgcn_readfirstlane(cpos);
+    const int8_t* gP = gP0 + kt0u * FBK;
+    const int8_t* gQ = gQ0 + x_off(kt0u);
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto dma_item = [&](int buf, auto gc) {      // piece g of the next K-tile: 0..3 P, 4..7 Q; the 8th moves the K walk on
         constexpr int g = decltype(gc)::value;
@@ -1161,9 +1170,9 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
                     cleft = clen;
                     cpos = clen > 0 ? rot_of(clen) : 0;
                 }
-                const int koff = __builtin_amdgcn_readfirstlane((cbase + cpos) * FBK);
-                gP = gP0 + koff;
-                gQ = gQ0 + koff;
+                const int ktu = __builtin_amdgcn_readfirstlane(cbase + cpos);
+                gP = gP0 + ktu * FBK;
+                gQ = gQ0 + x_off(ktu);
             }
         }
     };
@@ -1331,7 +1340,13 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
 
 template <int OUT>
 void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N,
-                         int64_t K, hipStream_t st) {
+                         int64_t K, hipStream_t st, int64_t a_slab_stride, int64_t a_k_per_slab) {
+    KSlabs xs{};
+    if (a_k_per_slab > 0) {          // stacked activation operand (the caller checked: LC form, k_per_slab % 128 == 0, K / 128 < 2^16)
+        xs.tiles = (int)(a_k_per_slab / FBK);
+        xs.magic = (uint32_t)(((1ull << 32) + (uint64_t)xs.tiles - 1) / (uint64_t)xs.tiles);
+        xs.stride = a_slab_stride;
+    }
     const int tiles_m = (int)((M + R_TILE - 1) / R_TILE), tiles_n = (int)((N + R_TILE - 1) / R_TILE);
     // K rotation (LC form), chunks of rot_chunk_ktiles() K-tiles: HBM-fed launches lose their lockstep penalty — 4096 x 1024 x 8192 37.5 -> 33.9 us, 2048 x 1024 x 8192
     // 34.4 -> 26.8, 4096 x 1024 x 28672 127.6 -> 102.4 — for 4 - 5 % on cache-warm replays; PQ_RING_ROT=0 switches it off (A/B: profiles/r04_rotation.txt)
@@ -1349,13 +1364,13 @@ void launch_gemm_ring128(const int8_t* A, int64_t lda, const int8_t* B, int64_t 
         }
     }
 #endif
-    if (opt().ring_lc) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div, nullptr);
+    if (opt().ring_lc || xs.tiles > 0) gemm_s8_ring128<OUT, true><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rot_div, nullptr, xs);
     else gemm_s8_ring128<OUT, false><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 1 << 30, 0, nullptr);
 }
-template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ring128<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ring128<OUT_I32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_ring128<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ring128<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ring128<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ring128<OUT_I32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
 
 #define PQ_INST(OUT, TM, TN) \
     template void launch_gemm_fast<OUT, TM, TN>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);

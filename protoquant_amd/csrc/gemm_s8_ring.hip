@@ -25,7 +25,7 @@ namespace pq {
 // 64 x 64 tile has per K-tile)
 template <int OUT, int TM, int TN, int NB, int KT>
 __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict__ X, int64_t ldx, const int8_t* __restrict__ W, int64_t ldw,
-                                                        EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div) {
+                                                        EpiArgs epi, int M, int N, int K, int tiles_m, int tiles_n, int ct, int rot_div, KSlabs xs = KSlabs{}) {
     constexpr int P_OPER = TN * FBK, Q_OPER = TM * FBK, BUF = P_OPER + Q_OPER;
     constexpr int PPW = TN / 32, QPW = TM / 32, PPT = PPW + QPW;      // 1-KiB DMA pieces per loader wave per K-tile: P side, Q side, both
     constexpr int NPI = TN / 32, NQJ = TM / 32;                       // 16 x 16 tiles of a consumer's wave block: along n, along m
@@ -80,9 +80,15 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     const int8_t* const gQ0 = X + (int64_t)m0 * ldx;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto stage1 = [&](uint32_t la) {                           // this loader wave's pieces of its next K-tile, then the K walk moves on
-        const int koff = __builtin_amdgcn_readfirstlane((cbase + cpos) * FBK);      // (the rotation's division is vector code; the DMA's base operand must be provably wave-uniform)
-        const int8_t* gP = gP0 + koff;
-        const int8_t* gQ = gQ0 + koff;
+        const int ktu = __builtin_amdgcn_readfirstlane(cbase + cpos);      // (the rotation's division is vector code; the DMA's base operand must be provably wave-uniform)
+        const int8_t* gP = gP0 + ktu * FBK;
+        // X stacked in K-slabs (pq_qlinear_s8_kslabs, as in gemm_s8_ring128): K-tile kt lives in slab kt / xs.tiles; the division by a host-computed reciprocal, all scalar
+        int64_t xo = (int64_t)ktu * FBK;
+        if (xs.tiles > 0) {
+            const int sl = (int)(((uint64_t)(uint32_t)ktu * (uint64_t)xs.magic) >> 32);
+            xo = (int64_t)sl * xs.stride + (int64_t)(ktu - sl * xs.tiles) * FBK;
+        }
+        const int8_t* gQ = gQ0 + xo;
 #pragma unroll
         for (int jj = 0; jj < PPW; ++jj) glds16_sbase(gP, offP[jj], la + (uint32_t)(w * PPW + jj) * 1024u);
 #pragma unroll
@@ -244,21 +250,28 @@ static void rot_plan(int tiles_m, int tn, int* ct, int* rot_div) {
 
 // tile: 0 = 64(m) x 128(n), 3 slots of 2 K-tiles (144 KiB); 1 = 64 x 64, 4 slots of 2 K-tiles (128 KiB)
 template <int OUT>
-void launch_gemm_ringt(int tile, const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+void launch_gemm_ringt(int tile, const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K, hipStream_t st,
+                       int64_t a_slab_stride, int64_t a_k_per_slab) {
     int ct = 0, rd = 0;
+    KSlabs xs{};
+    if (a_k_per_slab > 0) {          // stacked activation operand (the caller checked: k_per_slab % 128 == 0, K / 128 < 2^16)
+        xs.tiles = (int)(a_k_per_slab / FBK);
+        xs.magic = (uint32_t)(((1ull << 32) + (uint64_t)xs.tiles - 1) / (uint64_t)xs.tiles);
+        xs.stride = a_slab_stride;
+    }
     if (tile == 0) {
         const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 127) / 128);
         rot_plan(tiles_m < 8 ? tiles_m : 8, 128, &ct, &rd);
-        gemm_s8_ringt<OUT, 64, 128, 3, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd);
+        gemm_s8_ringt<OUT, 64, 128, 3, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd, xs);
     } else {
         const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 63) / 64);
         rot_plan(tiles_m < 8 ? tiles_m : 8, 64, &ct, &rd);
-        gemm_s8_ringt<OUT, 64, 64, 4, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd);
+        gemm_s8_ringt<OUT, 64, 64, 4, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd, xs);
     }
 }
-template void launch_gemm_ringt<PQ_BF16>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ringt<PQ_FP16>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ringt<PQ_F32>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template void launch_gemm_ringt<OUT_I32>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template void launch_gemm_ringt<PQ_BF16>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ringt<PQ_FP16>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ringt<PQ_F32>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
+template void launch_gemm_ringt<OUT_I32>(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t, int64_t);
 
 }  // namespace pq

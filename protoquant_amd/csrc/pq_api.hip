@@ -18,8 +18,9 @@ template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*,
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template <int OUT> void launch_gemm_ringt(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
+template <int DT, int MODE> void silu_mul_split_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
+template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
+template <int OUT> void launch_gemm_ringt(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
 template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
 template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
@@ -76,7 +77,7 @@ thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by
 thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_NO_KSLABS", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE", "PQ_SKINNY_KS"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
@@ -90,6 +91,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_FSK_FENCED")) o.fsk_fenced = set && *value == '1';
     else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_NO_MIDM")) o.no_midm = set;
+    else if (!strcmp(name, "PQ_NO_KSLABS")) o.no_kslabs = set;
     else if (!strcmp(name, "PQ_MIDM_CT")) o.midm_ct = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) o.rms_wave_max = !set || iv < 0 ? 256 : (iv > 512 ? 512 : iv);
     else if (!strcmp(name, "PQ_SILU_TPR")) o.silu_tpr = set && !strcmp(value, "256") ? 256 : 0;
@@ -279,6 +281,30 @@ bool bad_mat(const void* p, int64_t rows, int64_t cols, int64_t ld) {
 
 }  // namespace
 
+// ---- qlinear on STACKED activation codes (what an all-gather of the ranks' int8 column blocks leaves: [G][M][K / G])
+namespace {
+typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+// stacked[s][m][c] (slab stride in bytes, row length lda) -> out[m][s * kps + c], 16 bytes at a time (kps % 16 == 0, aligned bases) or byte by byte
+template <typename V>
+__global__ __launch_bounds__(256) void unstack_kslabs_kernel(const uint8_t* __restrict__ a, int64_t lda, int64_t slab_stride, uint8_t* __restrict__ out, int64_t ldo,
+                                                             int64_t M, int64_t kps_v, int nslabs) {
+    const int64_t total = (int64_t)nslabs * M * kps_v;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = i % kps_v, m = (i / kps_v) % M, sl = i / (kps_v * M);
+        *reinterpret_cast<V*>(out + m * ldo + (sl * kps_v + c) * (int64_t)sizeof(V)) = *reinterpret_cast<const V*>(a + sl * slab_stride + m * lda + c * (int64_t)sizeof(V));
+    }
+}
+// the stacked operand can be walked in place by the loaders of the ring tiles (gemm_s8_ring128, gemm_s8_ringt: KSlabs) when one of them is what the planner picks for the
+// shape and runs it single-pass; returns that variant, or V_GENERIC for "take the layout pass"
+Variant kslabs_in_place(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t kps, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    if (options().no_kslabs || forced_variant() != V_AUTO || kps % 128 != 0 || K / 128 >= 65536 || (slab_stride & 15) != 0) return V_GENERIC;
+    // (eligibility of the fast path is decided on the slab's own leading dimension and base; K itself is the whole K)
+    const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
+    return (v == V_RING128 || v == V_RING64X128 || v == V_RING64X64) ? v : V_GENERIC;
+}
+}  // namespace
+
+
 namespace pq {
 const Options& opt() { return options(); }
 }  // namespace pq
@@ -346,6 +372,39 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
         default: pq::silu_mul_quant_dispatch<PQ_F32>(g, ld_g, u, ld_u, rows, cols, q, ld_q, scale, h_out, ld_h, st); break;
     }
     return check_launch("pq_silu_mul_quant_rowwise");
+}
+
+int32_t pq_silu_mul_rowamax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
+                            uint32_t* amax_bits, void* stream) {
+    Range range_("pq:silu_mul_rowamax (K1s, amax half)");
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_rowamax: unknown dtype %d", dtype);
+    if (bad_mat(g, rows, cols, ld_g) || bad_mat(u, rows, cols, ld_u) || (rows > 0 && !amax_bits))
+        return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_rowamax: bad matrix (rows=%lld cols=%lld ld_g=%lld ld_u=%lld)", (long long)rows, (long long)cols, (long long)ld_g, (long long)ld_u);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+    }
+    return check_launch("pq_silu_mul_rowamax");
+}
+
+int32_t pq_silu_mul_quant_rowwise_amax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
+                                       const uint32_t* amax_bits, int8_t* q, int64_t ld_q, float* scale, void* stream) {
+    Range range_("pq:silu_mul_quant_amax (K1s, encode half)");
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_quant_rowwise_amax: unknown dtype %d", dtype);
+    if (bad_mat(g, rows, cols, ld_g) || bad_mat(u, rows, cols, ld_u) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && (!scale || !amax_bits)))
+        return fail(PQ_ERR_BAD_ARG, "pq_silu_mul_quant_rowwise_amax: bad matrix (rows=%lld cols=%lld ld_g=%lld ld_u=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_g, (long long)ld_u, (long long)ld_q);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* ab = const_cast<uint32_t*>(amax_bits);          // (read-only in this mode)
+    switch (dtype) {
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+    }
+    return check_launch("pq_silu_mul_quant_rowwise_amax");
 }
 
 int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight, float eps, int32_t dtype, int64_t rows, int64_t cols,
@@ -543,8 +602,68 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
     return qlinear_core("pq_qlinear_s8_t", b, ldb, a, lda, epi, out_dtype, N, M, K, workspace, workspace_bytes, stream);
 }
 
-// ---- one-call dynamic qlinear: K1 (x -> xq, xs in the workspace) then pq_qlinear_s8 (with split-K slabs if planned).
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ---- qlinear on STACKED activation codes (helpers above, before the C-ABI block)
+size_t pq_qlinear_kslabs_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t k_per_slab) {
+    CallScope scope_;
+    if (M <= 0 || N <= 0 || K <= 0 || k_per_slab <= 0 || K % k_per_slab != 0) return 0;
+    if (K == k_per_slab) return pq_qlinear_workspace_bytes(M, N, K);
+    if (kslabs_in_place(reinterpret_cast<const int8_t*>(16), k_per_slab, M * k_per_slab, k_per_slab, reinterpret_cast<const int8_t*>(16), K, M, N, K) != V_GENERIC) return 0;
+    return align256((size_t)M * (size_t)K) + pq_qlinear_workspace_bytes(M, N, K);
+}
+
+int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const float* a_scale, const int8_t* b, int64_t ldb,
+                             const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M, int64_t N, int64_t K,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope_;
+    if (out_dtype < 0 || out_dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_kslabs: unknown dtype %d", out_dtype);
+    if (M < 0 || N < 0 || K < 0 || k_per_slab <= 0 || K % k_per_slab != 0 || bad_mat(a, M, k_per_slab, lda) || bad_mat(b, N, K, ldb) || bad_mat(y, M, N, ldy) ||
+        (M > 0 && !a_scale) || (N > 0 && !b_scale) || (K > k_per_slab && slab_stride < (M - 1) * lda + k_per_slab))
+        return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_kslabs: bad arguments (M=%lld N=%lld K=%lld k_per_slab=%lld lda=%lld slab_stride=%lld ldb=%lld ldy=%lld)", (long long)M, (long long)N,
+                    (long long)K, (long long)k_per_slab, (long long)lda, (long long)slab_stride, (long long)ldb, (long long)ldy);
+    if (M == 0 || N == 0) return PQ_OK;
+    if (K == k_per_slab) return pq_qlinear_s8(a, lda, a_scale, b, ldb, b_scale, bias, y, ldy, out_dtype, M, N, K, workspace, workspace_bytes, stream);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (const Variant v = kslabs_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K); v != V_GENERIC) {
+        Range range_("pq:qlinear_s8_kslabs (K3+K4, slabs walked in place)");
+        pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy, 0};
+        epi.y_any_align = options().epi_any_align ? 1 : 0;
+        if (!pq::epi_flags_valid(epi.flags, epi.bias != nullptr)) abort();
+        auto go = [&](auto oc) {
+            constexpr int OUT = decltype(oc)::value;
+            if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st, slab_stride, k_per_slab);
+            else pq::launch_gemm_ringt<OUT>(v == V_RING64X128 ? 0 : 1, a, lda, b, ldb, epi, M, N, K, st, slab_stride, k_per_slab);
+        };
+        switch (out_dtype) {
+            case PQ_BF16: go(std::integral_constant<int, PQ_BF16>{}); break;
+            case PQ_FP16: go(std::integral_constant<int, PQ_FP16>{}); break;
+            default: go(std::integral_constant<int, PQ_F32>{}); break;
+        }
+        return check_launch("pq_qlinear_s8_kslabs");
+    }
+    // any other shape: one layout pass into the caller's workspace (reads + writes M * K bytes), then the planner's own choice on row-major codes
+    const size_t need_a = align256((size_t)M * (size_t)K), need = need_a + pq_qlinear_workspace_bytes(M, N, K);
+    if (!workspace || workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8_kslabs: workspace %zu < %zu bytes", workspace ? workspace_bytes : (size_t)0, need);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(PQ_ERR_BAD_ALIGN, "pq_qlinear_s8_kslabs: workspace must be 256-byte aligned");
+    uint8_t* flat = static_cast<uint8_t*>(workspace);
+    {
+        Range range_("pq:unstack_kslabs");
+        const int nslabs = (int)(K / k_per_slab);
+        const bool vec = (k_per_slab % 16 == 0) && (lda % 16 == 0) && (slab_stride % 16 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+        const int64_t units = (int64_t)M * K / (vec ? 16 : 1);
+        int64_t blocks = (units + 255) / 256;
+        blocks = blocks > 256 * 16 ? 256 * 16 : (blocks < 1 ? 1 : blocks);
+        if (vec) unstack_kslabs_kernel<v4u_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(reinterpret_cast<const uint8_t*>(a), lda, slab_stride, flat, K, M, k_per_slab / 16, nslabs);
+        else unstack_kslabs_kernel<uint8_t><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(reinterpret_cast<const uint8_t*>(a), lda, slab_stride, flat, K, M, k_per_slab, nslabs);
+        const int32_t rc = check_launch("pq_qlinear_s8_kslabs (layout pass)");
+        if (rc != PQ_OK) return rc;
+    }
+    const size_t rest = workspace_bytes - need_a;
+    return pq_qlinear_s8(reinterpret_cast<const int8_t*>(flat), K, a_scale, b, ldb, b_scale, bias, y, ldy, out_dtype, M, N, K, rest ? flat + need_a : nullptr, rest, stream);
+}
+
+// ---- one-call dynamic qlinear: K1 (x -> xq, xs in the workspace) then pq_qlinear_s8 (with split-K slabs if planned).
 
 size_t pq_qlinear_dyn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     CallScope scope_;

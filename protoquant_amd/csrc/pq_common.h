@@ -29,6 +29,7 @@ struct Options {
     int fsk = -1;                    // fused split-K: -1 = by plan (fsk_plan), 0 = never, S > 1 = S slices whenever the shape admits them (experiments)
     bool fsk_symmetric = false;      // PQ_FSK_SYMMETRIC=1: the symmetric exchange for 2 / 4 slices (waits for partner workgroups: see pq_hip.h); default: the ticket form
     int midm_ct = 0;                 // PQ_MIDM_CT: K-tiles per rotation chunk of the mid-M ring tiles (0 = by rule, 1 = no rotation)
+    bool no_kslabs = false;          // PQ_NO_KSLABS=1: pq_qlinear_s8_kslabs always takes the layout pass (never walks the slabs in place)
     bool no_midm = false;            // PQ_NO_MIDM=1: no 64-row ring tiles for 64 < M <= 512 (the round-3 dispatch)
     bool fsk_fenced = false;         // PQ_FSK_FENCED=1: the ticket hand-over with the documented agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) as well
     int fake_cus = 0;                // PQ_FAKE_CUS=n: plan as if the device had n CUs (tests of the residency guard)

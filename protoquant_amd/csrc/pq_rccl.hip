@@ -335,6 +335,24 @@ int32_t pq_allgather_rows_t(void* comm, const void* yt_shard, void* yt_full, int
     return 0;
 }
 
+int32_t pq_allreduce_max_u32(void* comm, uint32_t* buf, int64_t count, void* stream) {
+    Range range_("pq:allreduce_max_u32");
+    if (!comm || count < 0) return fail(1, "pq_allreduce_max_u32: bad arguments");
+    if (count == 0) return 0;
+    if (!buf) return fail(1, "pq_allreduce_max_u32: null buffer");
+    const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclUint32, ncclMax, H(comm)->c, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : fail(6, "ncclAllReduce: %s", ncclGetErrorString(r));
+}
+
+int32_t pq_allgather_bytes(void* comm, const void* shard, void* stacked, int64_t bytes, void* stream) {
+    Range range_("pq:allgather_bytes");
+    if (!comm || bytes < 0) return fail(1, "pq_allgather_bytes: bad arguments");
+    if (bytes == 0) return 0;
+    if (!shard || !stacked) return fail(1, "pq_allgather_bytes: null buffer");
+    const ncclResult_t r = ncclAllGather(shard, stacked, (size_t)bytes, ncclInt8, H(comm)->c, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : fail(6, "ncclAllGather: %s", ncclGetErrorString(r));
+}
+
 size_t pq_reduce_scatter_rows_workspace_bytes(int32_t nranks, int64_t m_shard, int64_t N, int32_t out_dtype) {
     if (nranks < 1 || m_shard < 0 || N < 0 || out_dtype < 0 || out_dtype > 2) return 0;
     return out_dtype == 2 ? 0 : (size_t)m_shard * (size_t)N * sizeof(float);

@@ -223,14 +223,15 @@ __device__ __forceinline__ void fast_encode_vec(const v4u& hv, float s, float r,
         pk[k] = __builtin_amdgcn_perm(mb[4 * k + 1], mb[4 * k], 0x0c0c0400u) | __builtin_amdgcn_perm(mb[4 * k + 3], mb[4 * k + 2], 0x04000c0cu);
 }
 
-// The second half of K1, shared by the producer-fused kernels: row amax of the h vectors held in registers (bit-pattern
-// max: a NaN propagates into the scale), scale, and the division-free exact encode (or the true-division
-// path for NaN/Inf data and extreme scales).  TPR threads own the row; t = thread's index in the row.
-template <int DT, int VPT, int TPR>
-__device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t ab, int t, int nvec, bool active, int64_t row,
-                                                  int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
-    constexpr int EPV = 16 / Elem<DT>::kBytes;
-    ab = wave_max_u32(amax_acc_finish<DT>(ab));       // `ab` arrives as vec_amax_bits' accumulator
+// The second half of K1, shared by the producer-fused kernels, in two steps: the row amax of the h vectors held in registers (bit-pattern
+// max: a NaN propagates into the scale) as an f32 bit pattern, then scale + the division-free exact encode (or the true-division
+// path for NaN/Inf data and extreme scales) for a GIVEN row amax.  TPR threads own the row; t = thread's index in the row.
+// The split is what the column-sharded gated MLP needs (pq_silu_mul_rowamax / pq_silu_mul_quant_rowwise_amax): a rank holds only I/G of a
+// token's intermediate channels, the row amax is an exact max over the ranks (an integer max of these bit patterns), and the encode
+// then runs locally against the GLOBAL amax — the codes are the unsharded kernel's, bit for bit.
+template <int DT, int TPR>
+__device__ __forceinline__ uint32_t row_amax_f32_bits(uint32_t ab) {           // `ab` arrives as vec_amax_bits' accumulator
+    ab = wave_max_u32(amax_acc_finish<DT>(ab));
     constexpr int NW = (TPR > 256 ? TPR : 256) / kWave;      // waves of the block (a row group wider than a wave is the whole block)
     __shared__ uint32_t part[NW];
     if constexpr (TPR > kWave) {
@@ -239,8 +240,15 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
 #pragma unroll
         for (int w = 0; w < NW; ++w) ab = part[w] > ab ? part[w] : ab;
     }
-    const bool has_nan = amax_bits_has_nan<DT>(ab);          // QSPEC v2: a NaN propagates (scale = canonical NaN, codes 0 by the true-division path)
-    const float s = scale_of(amax_bits_to_f32<DT>(ab));
+    // widened to the f32 pattern of the same value: non-negative floats (and NaNs, which sort above +Inf) order as unsigned integers in every format
+    return __builtin_bit_cast(uint32_t, amax_bits_to_f32<DT>(ab)) & 0x7FFFFFFFu;
+}
+template <int DT, int VPT, int TPR>
+__device__ __forceinline__ void encode_with_amax(const v4u (&hv)[VPT], uint32_t amax_f32_bits, int t, int nvec, bool active, int64_t row,
+                                                 int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const bool has_nan = amax_f32_bits > 0x7F800000u;        // QSPEC v2: a NaN propagates (scale = canonical NaN, codes 0 by the true-division path)
+    const float s = scale_of(__builtin_bit_cast(float, amax_f32_bits));
     if (!active) return;
     if (t == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
@@ -271,15 +279,22 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
         }
     }
 }
+template <int DT, int VPT, int TPR>
+__device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t ab, int t, int nvec, bool active, int64_t row,
+                                                  int8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
+    encode_with_amax<DT, VPT, TPR>(hv, row_amax_f32_bits<DT, TPR>(ab), t, nvec, active, row, q, ldq, scale);
+}
 
 // TPR = 512 (a 512-thread block per row, wide rows): round 1 held such rows with 256 threads x 8 vectors of g and of u —
 // 143 VGPRs, 3 waves per SIMD in a kernel that is VALU-bound before it is HBM-bound; 512 threads x 3-4 vectors need < 100.
-template <int DT, int VPT, int TPR, bool WRITE_H>
+// MODE 0: K1s (amax + encode).  MODE 1: the row amax only (amax_io[row] = f32 bit pattern of max |h| over these columns; nothing else is written).
+// MODE 2: encode against the row amax GIVEN in amax_io (the max over every rank's columns): no reduction; writes codes and the scale.
+template <int DT, int VPT, int TPR, bool WRITE_H, int MODE = 0>
 __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
                                                           const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
                                                           int nvec, int8_t* __restrict__ q, int64_t ldq,
                                                           float* __restrict__ scale, uint8_t* __restrict__ h_out,
-                                                          int64_t ldh_bytes) {
+                                                          int64_t ldh_bytes, uint32_t* __restrict__ amax_io = nullptr) {
     constexpr int BS = TPR > 256 ? TPR : 256;
     constexpr int RPB = BS / TPR;
     const int t = threadIdx.x % TPR;
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(cons
             const int idx = i * TPR + t;
             // slots past the row's end (whole waves of them when the width is not VPT * TPR vectors) skip the arithmetic
             hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
-            ab = vec_amax_bits<DT>(hv[i], ab);
+            if constexpr (MODE != 2) ab = vec_amax_bits<DT>(hv[i], ab);
             if constexpr (WRITE_H) {
                 if (active && idx < nvec) store_wt_b128(h_out + row * ldh_bytes + (int64_t)idx * 16, hv[i]);
             }
@@ -318,31 +333,47 @@ __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(cons
     };
     if (fast_div) produce(std::true_type{});
     else produce(std::false_type{});
-    reduce_and_encode<DT, VPT, TPR>(hv, ab, t, nvec, active, row, q, ldq, scale);
+    if constexpr (MODE == 1) {
+        const uint32_t fb = row_amax_f32_bits<DT, TPR>(ab);
+        if (active && t == 0) amax_io[row] = fb;
+    } else if constexpr (MODE == 2) {
+        encode_with_amax<DT, VPT, TPR>(hv, amax_io[row], t, nvec, active, row, q, ldq, scale);
+    } else {
+        reduce_and_encode<DT, VPT, TPR>(hv, ab, t, nvec, active, row, q, ldq, scale);
+    }
 }
 
 // generic path: any cols / leading dimensions / alignment.  One block per row; h is recomputed in the second pass.
-template <int DT>
+template <int DT, int MODE = 0>
 __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __restrict__ g, int64_t ldg, const void* __restrict__ u,
                                                               int64_t ldu, int64_t cols, int8_t* __restrict__ q, int64_t ldq,
-                                                              float* __restrict__ scale, void* __restrict__ h_out, int64_t ldh) {
+                                                              float* __restrict__ scale, void* __restrict__ h_out, int64_t ldh,
+                                                              uint32_t* __restrict__ amax_io = nullptr) {
     using S = typename Elem<DT>::store_t;
     const int64_t row = blockIdx.x;
     const S* gr = reinterpret_cast<const S*>(g) + row * ldg;
     const S* ur = reinterpret_cast<const S*>(u) + row * ldu;
     auto h_at = [&](int64_t c) -> S { return Elem<DT>::from_f32(silu_mul_spec<DT>(Elem<DT>::to_f32(gr[c]), Elem<DT>::to_f32(ur[c]))); };
     float amax = 0.0f;
-    for (int64_t c = threadIdx.x; c < cols; c += 256) {
-        const S h = h_at(c);
-        if (h_out) reinterpret_cast<S*>(h_out)[row * ldh + c] = h;
-        amax = amax_step(amax, Elem<DT>::to_f32(h));
-    }
-    amax = wave_max(amax);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
-    __syncthreads();
+    if constexpr (MODE == 2) {
+        amax = __builtin_bit_cast(float, amax_io[row]);
+    } else {
+        for (int64_t c = threadIdx.x; c < cols; c += 256) {
+            const S h = h_at(c);
+            if (h_out) reinterpret_cast<S*>(h_out)[row * ldh + c] = h;
+            amax = amax_step(amax, Elem<DT>::to_f32(h));
+        }
+        amax = wave_max(amax);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
+        __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) amax = amax_merge(amax, part[w]);
+        for (int w = 0; w < 4; ++w) amax = amax_merge(amax, part[w]);
+    }
+    if constexpr (MODE == 1) {
+        if (threadIdx.x == 0) amax_io[row] = __builtin_bit_cast(uint32_t, amax);
+        return;
+    }
     const float s = scale_of(amax);
     if (threadIdx.x == 0) scale[row] = s;
     int8_t* qr = q + row * ldq;
@@ -549,25 +580,49 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 // vectors the 256-thread block per row (2 vectors per thread, ~44 VGPRs) is 10 % faster at 4096 rows (15.7 -> 14.2 us) and equal at 16384;
 // at 256 vectors the wave layout wins (8.7 vs 9.6 us).  Same bits either way (QSPEC N1-N3 pins the order of the sum).
 
-template <int DT, int TPR, bool WRITE_H>
+template <int DT, int TPR, bool WRITE_H, int MODE = 0>
 static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const uint8_t* u, int64_t ldu_b, int64_t rows, int nvec,
-                                int8_t* q, int64_t ldq, float* scale, uint8_t* h, int64_t ldh_b, hipStream_t st) {
+                                int8_t* q, int64_t ldq, float* scale, uint8_t* h, int64_t ldh_b, hipStream_t st, uint32_t* amax_io = nullptr) {
     constexpr int BS = TPR > 256 ? TPR : 256, RPB = BS / TPR;
     const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(BS);
     switch (vpt) {
-        case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
-        case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
+        case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
         case 3:
-            if constexpr (TPR == 512) silu_mul_quant_vec<DT, 3, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            if constexpr (TPR == 512) silu_mul_quant_vec<DT, 3, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
-        case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b); break;
+        case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
         case 8:
-            if constexpr (TPR != 512) silu_mul_quant_vec<DT, 8, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            if constexpr (TPR != 512) silu_mul_quant_vec<DT, 8, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
         default:
-            if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b);
+            if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
     }
+}
+
+// the two halves of K1s for a column-sharded intermediate (MODE 1: row amax of these columns -> amax_io; MODE 2: encode against the amax in amax_io).
+// Same layouts as the fused kernel (the h vectors are recomputed in MODE 2 — g and u are read twice, from the Infinity Cache the second time — instead of
+// parking a 16-bit h in HBM between the two passes: the same 9 bytes per element either way, and no extra buffer).
+template <int DT, int MODE>
+void silu_mul_split_dispatch(const void* g, int64_t ldg, const void* u, int64_t ldu, int64_t rows, int64_t cols, uint32_t* amax_io, int8_t* q,
+                             int64_t ldq, float* scale, hipStream_t st) {
+    static_assert(MODE == 1 || MODE == 2, "split modes");
+    constexpr int EPV = 16 / Elem<DT>::kBytes;
+    const bool vec_ok = cols > 0 && (cols % EPV == 0) && (ldg % EPV == 0) && (ldu % EPV == 0) && aligned_to(g, 16) && aligned_to(u, 16) &&
+                        cols / EPV <= 256 * 16 && (MODE == 1 || ((ldq % EPV == 0) && aligned_to(q, EPV)));
+    if (!vec_ok) {
+        silu_mul_quant_generic<DT, MODE><<<dim3((unsigned)rows), dim3(256), 0, st>>>(g, ldg, u, ldu, cols, q, ldq, scale, nullptr, 0, amax_io);
+        return;
+    }
+    const int nvec = (int)(cols / EPV);
+    auto pow2 = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
+    const uint8_t* gb = reinterpret_cast<const uint8_t*>(g);
+    const uint8_t* ub = reinterpret_cast<const uint8_t*>(u);
+    const int64_t kb = Elem<DT>::kBytes;
+    if (nvec <= 64 * 4) launch_silu_mul_vec<DT, 64, false, MODE>(pow2((nvec + 63) / 64), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
+    else if (nvec > 1024 && nvec <= 1536 && opt().silu_tpr != 256) launch_silu_mul_vec<DT, 512, false, MODE>((nvec + 511) / 512, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
+    else launch_silu_mul_vec<DT, 256, false, MODE>(pow2((nvec + 255) / 256), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
 }
 
 template <int DT>
@@ -656,6 +711,11 @@ template void rmsnorm_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*,
 template void rmsnorm_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template void rmsnorm_quant_dispatch<PQ_F32>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 
+#define PQ_SPLIT_INST(DT) \
+    template void silu_mul_split_dispatch<DT, 1>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t); \
+    template void silu_mul_split_dispatch<DT, 2>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
+PQ_SPLIT_INST(PQ_BF16) PQ_SPLIT_INST(PQ_FP16) PQ_SPLIT_INST(PQ_F32)
+#undef PQ_SPLIT_INST
 template void silu_mul_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template void silu_mul_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 template void silu_mul_quant_dispatch<PQ_F32>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);

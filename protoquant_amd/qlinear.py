@@ -161,6 +161,40 @@ def qlinear_s8_t(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch
     return yt
 
 
+def qlinear_s8_kslabs(xq_stacked: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+    """qlinear_s8 on STACKED activation codes xq_stacked[G, M, K/G] (contiguous: what an all-gather of the ranks' int8 column blocks leaves): slab s holds the
+    columns [s*K/G, (s+1)*K/G) of the logical xq[M, K].  Same bits as qlinear_s8 on the row-major matrix (an integer sum has no order); the 128 x 128 ring tile
+    walks the slabs in place, every other shape takes one layout pass inside the call (C-ABI pq_qlinear_s8_kslabs)."""
+    L.require_gpu(xq_stacked, "qlinear_s8_kslabs(xq)")
+    if xq_stacked.dim() != 3 or not xq_stacked.is_contiguous():
+        raise ValueError("qlinear_s8_kslabs: activation codes must be a contiguous [G, M, K/G] int8 tensor")
+    G, M, kps = xq_stacked.shape
+    K = G * kps
+    wq = L.row_major_2d(wq)
+    N = wq.shape[0]
+    if wq.shape[1] != K:
+        raise ValueError(f"shape mismatch: stacked x has K={K}, weight has K={wq.shape[1]}")
+    code = L.dtype_code(out_dtype)
+    if bias is not None and bias.dtype != out_dtype:
+        bias = bias.to(out_dtype)
+    dev = xq_stacked.device
+    _check_operand(xq_stacked, "xq", dev, torch.int8); _check_operand(wq, "wq", dev, torch.int8)
+    _check_operand(xs, "xs", dev, torch.float32, M); _check_operand(ws, "ws", dev, torch.float32, N)
+    if bias is not None:
+        _check_operand(bias, "bias", dev, out_dtype, N)
+    if out is not None and (out.device != dev or out.dtype != out_dtype or out.shape != (M, N) or (N > 1 and out.stride(1) != 1)):
+        raise ValueError(f"out must be a row-major [{M}, {N}] {out_dtype} tensor on {dev}")
+    y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=dev)
+    wbytes = L.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps)
+    wsp = _workspace(dev, wbytes) if wbytes else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().pq_qlinear_s8_kslabs(xq_stacked.data_ptr(), kps, M * kps, kps, xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
+                                             bias.data_ptr() if bias is not None else None, y.data_ptr(), L.ld(y), code, M, N, K,
+                                             wsp.data_ptr() if wsp is not None else None, wbytes, L.stream_ptr(xq_stacked)), "qlinear_s8_kslabs")
+    return y
+
+
 def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) -> torch.Tensor:
     """x[..., K] -> y[..., N]: dynamic per-token quant + int8 GEMM + fused dequant in ONE C-ABI call (pq_qlinear_dyn);
     the scratch (xq, xs, split-K slabs) lives in the per-device workspace."""

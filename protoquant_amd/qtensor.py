@@ -104,6 +104,45 @@ def silu_mul_quantize(g: torch.Tensor, u: torch.Tensor, return_h: bool = False):
     return (qt, h.reshape(g.shape)) if return_h else qt
 
 
+def _silu_pair(g, u, what):
+    L.require_gpu(g, f"{what}(g)")
+    L.require_gpu(u, f"{what}(u)")
+    if g.shape != u.shape or g.dtype != u.dtype or g.device != u.device or g.dim() < 1:
+        raise ValueError(f"{what}: g {tuple(g.shape)} {g.dtype} and u {tuple(u.shape)} {u.dtype} must match")
+    return L.dtype_code(g.dtype), _rows_view(g), _rows_view(u)
+
+
+def silu_mul_rowamax(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """First half of silu_mul_quantize for a column-sharded intermediate: per token, the f32 BIT PATTERN (int32 tensor [rows]) of max |silu(g)*u| over the
+    columns this rank holds.  Non-negative floats (and NaNs, above +Inf) order as integers: an integer MAX over the ranks is the exact row amax."""
+    code, g2, u2 = _silu_pair(g, u, "silu_mul_rowamax")
+    rows, cols = g2.shape
+    amax = torch.empty((rows,), dtype=torch.int32, device=g.device)
+    with torch.cuda.device(g.device):
+        L.check(L.lib().pq_silu_mul_rowamax(g2.data_ptr(), L.ld(g2), u2.data_ptr(), L.ld(u2), code, rows, cols, amax.data_ptr(), L.stream_ptr(g)), "silu_mul_rowamax")
+    return amax
+
+
+def silu_mul_quantize_with_amax(g: torch.Tensor, u: torch.Tensor, amax_bits: torch.Tensor, out: torch.Tensor | None = None) -> QTensor:
+    """Second half: the int8 codes of THESE columns against the row amax given as f32 bit patterns (int32 [rows], the max over every rank's columns), and the
+    row scales amax / 127.  Column block and scale vector of the unsharded silu_mul_quantize, bit for bit.  `out`: optional int8 [rows, cols] destination."""
+    code, g2, u2 = _silu_pair(g, u, "silu_mul_quantize_with_amax")
+    rows, cols = g2.shape
+    if amax_bits.dtype != torch.int32 or amax_bits.shape != (rows,) or amax_bits.device != g.device or not amax_bits.is_contiguous():
+        raise ValueError(f"silu_mul_quantize_with_amax: amax_bits must be a contiguous int32 [{rows}] tensor on {g.device}")
+    if out is None:
+        q = torch.empty((rows, cols), dtype=torch.int8, device=g.device)
+    else:
+        q = out
+        if q.dtype != torch.int8 or q.shape != (rows, cols) or q.device != g.device or (cols > 1 and q.stride(1) != 1):
+            raise ValueError(f"silu_mul_quantize_with_amax: out must be an int8 [{rows}, {cols}] tensor with contiguous rows")
+    scale = torch.empty((rows,), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        L.check(L.lib().pq_silu_mul_quant_rowwise_amax(g2.data_ptr(), L.ld(g2), u2.data_ptr(), L.ld(u2), code, rows, cols, amax_bits.data_ptr(),
+                                                       q.data_ptr(), L.ld(q) if rows > 1 else max(cols, 1), scale.data_ptr(), L.stream_ptr(g)), "silu_mul_quantize_with_amax")
+    return QTensor(q if out is not None else q.reshape(g.shape), scale, 1, g.dtype, g.shape)
+
+
 def rmsnorm_quantize(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, return_h: bool = False):
     """quantize(weight * (x.float() * rsqrt(mean(x.float()**2, -1) + eps)).to(x.dtype), axis=-1) in ONE pass (kernel K1
     fused into RMSNorm): the normalised activation feeding q/k/v or gate/up is reduced, scaled and encoded in registers.

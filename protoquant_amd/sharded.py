@@ -16,8 +16,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from .qlinear import FusedQLinear, gemm_operands, qlinear, qlinear_s8, qlinear_s8_t
-from .qtensor import QTensor, quantize, silu_mul_quantize
+from .qlinear import FusedQLinear, gemm_operands, qlinear, qlinear_s8, qlinear_s8_kslabs, qlinear_s8_t
+from .qtensor import QTensor, quantize, silu_mul_quantize, silu_mul_quantize_with_amax, silu_mul_rowamax
 
 
 def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
@@ -185,6 +185,29 @@ class RcclColumnGather:
                                                             L.stream_ptr(yt_local)), "pq_allgather_rows_t")
         return out
 
+    def allreduce_max_(self, bits: torch.Tensor) -> torch.Tensor:
+        """In-place exact MAX over the ranks of an int32 tensor of non-negative-float bit patterns (pq_allreduce_max_u32: ncclUint32 / ncclMax)."""
+        from . import _lib as L
+        if bits.dtype != torch.int32 or not bits.is_contiguous():
+            raise ValueError("allreduce_max_: a contiguous int32 tensor of f32 bit patterns is expected")
+        with torch.cuda.device(bits.device):
+            self._R.check(self._R.lib().pq_allreduce_max_u32(self._comm, bits.data_ptr(), bits.numel(), L.stream_ptr(bits)), "pq_allreduce_max_u32")
+        return bits
+
+    def gather_stacked(self, shard: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Contiguous all-gather of equal blocks: shard[...] (any dtype, contiguous) -> out[world, ...] (pq_allgather_bytes: no staging, no layout pass)."""
+        from . import _lib as L
+        if not shard.is_contiguous():
+            raise ValueError("gather_stacked: the shard must be contiguous")
+        if out is None:
+            out = torch.empty((self.world, *shard.shape), dtype=shard.dtype, device=shard.device)
+        elif out.shape != (self.world, *shard.shape) or out.dtype != shard.dtype or out.device != shard.device or not out.is_contiguous():
+            raise ValueError(f"gather_stacked: out must be a contiguous {(self.world, *shard.shape)} {shard.dtype} tensor")
+        with torch.cuda.device(shard.device):
+            self._R.check(self._R.lib().pq_allgather_bytes(self._comm, shard.data_ptr(), out.data_ptr(), shard.numel() * shard.element_size(), L.stream_ptr(shard)),
+                          "pq_allgather_bytes")
+        return out
+
     def close(self):
         if self._comm:
             self._R.check(self._R.lib().pq_comm_destroy(self._comm), "pq_comm_destroy")
@@ -302,6 +325,101 @@ class ColumnShardedQLinear(nn.Module):
         else:
             y = gather_columns(y_local, self.out_features, self.group)
         return y.reshape(*x.shape[:-1], self.out_features)
+
+
+class ColumnShardedGatedMLP(nn.Module):
+    """The gated MLP with gate, up AND down column-sharded (north_star's scheme for BASELINE config 5) and an INT8-CODE exchange between them.  The plain composition —
+    gather the bf16 gate and up shards, silu*mul and quantise the gathered [M, I] activation on every rank — moves 4 bytes per intermediate element and
+    repeats the quantisation G times.  Here, per token: silu*mul is column-local, so every rank computes the amax of ITS I/G columns (pq_silu_mul_rowamax); the row amax
+    is an exact max, so ONE all-reduce(max) of M 32-bit patterns makes it global; every rank encodes its own columns against it (pq_silu_mul_quant_rowwise_amax) and
+    the int8 blocks [M, I/G] are all-gathered — 1 byte per element, each column quantised once.  The gather leaves the blocks STACKED [G, M, I/G]; the down shard's GEMM
+    walks them in place (pq_qlinear_s8_kslabs: an integer sum has no order), so no layout pass follows.  Codes, scales and output are the unsharded GatedMLP's, bit
+    for bit (max is exact and order-free; S1-S5 are per element).  The output shards [M, H/G] are gathered like any ColumnShardedQLinear's.
+    Needs intermediate % world == 0.  native: an RcclColumnGather (libpq_rccl.so) — otherwise torch.distributed collectives."""
+
+    def __init__(self, gate_up_local: FusedQLinear, down_local: qlinear, hidden: int, intermediate: int, group=None, native: "RcclColumnGather | None" = None,
+                 world: int | None = None, rank: int | None = None):
+        super().__init__()
+        self.gate_up, self.down = gate_up_local, down_local
+        self.hidden, self.intermediate, self.group, self.native = hidden, intermediate, group, native
+        if native is not None:
+            world, rank = native.world, native.rank
+        elif world is None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.world, self.rank = world, rank
+        if intermediate % world:
+            raise ValueError(f"ColumnShardedGatedMLP: intermediate size {intermediate} is not a multiple of the world size {world} (the stacked code blocks must be equal)")
+
+    @classmethod
+    def from_linears(cls, gate: nn.Linear, up: nn.Linear, down: nn.Linear, group=None, native=None, world=None, rank=None) -> "ColumnShardedGatedMLP":
+        if (world is None) != (rank is None):
+            raise ValueError("ColumnShardedGatedMLP.from_linears: pass world and rank together (or neither: the process group's)")
+        if world is None:
+            world, rank = (native.world, native.rank) if native is not None else (dist.get_world_size(group), dist.get_rank(group))
+
+        def rows(lin, lo, hi):
+            sub = nn.Linear(lin.in_features, hi - lo, bias=lin.bias is not None, device=lin.weight.device, dtype=lin.weight.dtype)
+            with torch.no_grad():
+                sub.weight.copy_(lin.weight[lo:hi])
+                if lin.bias is not None:
+                    sub.bias.copy_(lin.bias[lo:hi])
+            return sub
+        ilo, ihi = shard_bounds(gate.out_features, world, rank)
+        hlo, hhi = shard_bounds(down.out_features, world, rank)
+        return cls(FusedQLinear.from_linears(rows(gate, ilo, ihi), rows(up, ilo, ihi)), qlinear.from_linear(rows(down, hlo, hhi)),
+                   down.out_features, gate.out_features, group, native, world, rank)
+
+    # ---- device steps (separate so that the host logic can be tested with them stubbed: tests/test_dist_gloo.py)
+    def _gate_up(self, x):
+        return self.gate_up(x)                                       # (g, u): this rank's I/G intermediate channels, one fused GEMM on the replicated input
+
+    def _local_amax(self, g, u):
+        return silu_mul_rowamax(g, u)
+
+    def _encode(self, g, u, amax_bits):
+        return silu_mul_quantize_with_amax(g, u, amax_bits)
+
+    def _down(self, stacked, scale, dtype):
+        return qlinear_s8_kslabs(stacked, scale, self.down.wq, self.down.ws, self.down.bias, dtype)
+
+    # ---- exchange steps
+    def _amax_allreduce(self, bits):
+        if self.world == 1:
+            return bits
+        if self.native is not None:
+            return self.native.allreduce_max_(bits)
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)      # int32 max == unsigned max here: every pattern has its sign bit clear
+        return bits
+
+    def _gather_codes(self, codes):
+        if self.native is not None:
+            return self.native.gather_stacked(codes)
+        out = codes.new_empty((self.world, *codes.shape))
+        if self.world == 1:
+            out[0].copy_(codes)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), codes.contiguous().view(-1), group=self.group)
+        return out
+
+    def _gather_out(self, y_local):
+        if self.native is not None:
+            return self.native(y_local, self.hidden)
+        if self.world == 1:
+            return y_local
+        return gather_columns(y_local, self.hidden, self.group)
+
+    def hidden_codes(self, x: torch.Tensor):
+        """(stacked int8 codes [G, M, I/G], row scales [M]) of the quantised silu(gate(x)) * up(x): the exchange half of forward()"""
+        g, u = self._gate_up(x)
+        g2, u2 = g.reshape(-1, g.shape[-1]), u.reshape(-1, u.shape[-1])
+        amax = self._amax_allreduce(self._local_amax(g2, u2))
+        hq = self._encode(g2, u2, amax)
+        return self._gather_codes(hq.int_data.reshape(g2.shape)), hq.scale
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        stacked, scale = self.hidden_codes(x)
+        y = self._gather_out(self._down(stacked, scale, x.dtype))
+        return y.reshape(*x.shape[:-1], self.hidden)
 
 
 # ---------------------------------------------------------------- row-sharded (K-split) qlinear + reduce-scatter

@@ -65,6 +65,32 @@ def main():
             assert torch.equal(bits(yr), bits(total[m0:m1].to(torch.bfloat16))), (rank, "reduce-scatter", M, N, K)
         else:
             assert torch.allclose(yr.float(), total[m0:m1], rtol=2e-2, atol=1e-3)
+    # the int8-code exchange of the column-sharded gated MLP: all-reduce(max) of the row-amax bit patterns, all-gather of the int8 code blocks, the down shard's GEMM on
+    # the stacked blocks, gather of the output shards — against the unsharded GatedMLP on this rank, bit for bit; eagerly and replayed from a hipGraph
+    for (M, H, I, bias) in ((300, 512, 1024, True), (4096, 1024, 8 * 896, False)):
+        if I % world or H % world:
+            continue
+        torch.manual_seed(11 + I)
+        lins = [torch.nn.Linear(i, o, bias=bias, device="cuda", dtype=torch.bfloat16) for (o, i) in ((I, H), (I, H), (H, I))]
+        x = torch.randn(M, H, device="cuda", dtype=torch.bfloat16)
+        x[1, 5] = float("nan")                                                       # a NaN token: must come through the integer max as a NaN row
+        y0 = pq.GatedMLP.from_linears(*lins)(x)
+        m = pq.ColumnShardedGatedMLP.from_linears(*lins, native=gather)
+        y1 = m(x)
+        torch.cuda.synchronize()
+        nan0 = torch.isnan(y0)
+        assert torch.equal(torch.isnan(y1), nan0) and bool(nan0[1].all()) and torch.equal(bits(y1)[~nan0], bits(y0)[~nan0]), (rank, "int8-code exchange", M, H, I)
+        out = torch.empty_like(y0)
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out.copy_(m(x))
+            for _ in range(3):
+                out.zero_(); g.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(bits(out)[~nan0], bits(y0)[~nan0]), (rank, "int8-code exchange, graph replay", M, H, I)
     dist.barrier()
     gather.close()
     dist.destroy_process_group()

@@ -226,3 +226,82 @@ def test_column_sharded_module_forward_world2(N, layout, chunks):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------- ColumnShardedGatedMLP.forward at world 2 (host logic + the three collectives over gloo)
+def _cgm_worker(rank, world, port, M, H, I, q):
+    """forward() of the int8-code exchange with its four device steps replaced by the numpy oracle (the HIP kernels: tests/test_gpu_int8_exchange.py): what runs here
+    is the real host logic — shard bounds, the integer all-reduce(max) of the amax bit patterns, the all-gather of the int8 blocks into the stacked layout, the gather
+    of the output shards — and the result must equal the oracle's UNSHARDED block (quantize(silu(g)*u) on whole rows, one GEMM over the whole K), bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from oracle import qspec_numpy as Q
+        from protoquant_amd.qtensor import QTensor
+        from protoquant_amd.sharded import ColumnShardedGatedMLP, shard_bounds
+
+        rng = np.random.default_rng(11)
+        f = lambda *shape, s=1.0: Q.from_f32((rng.standard_normal(shape) * s).astype(np.float32), 0)      # noqa: E731
+        x, wg, wu, wd = f(M, H), f(I, H, s=0.08), f(I, H, s=0.08), f(H, I, s=0.05)
+        x[1, 3] = 0x7FC0                                    # a NaN token: its amax must propagate through the integer max
+        (gq, gs), (uq, us), (dq, ds) = (Q.quantize(w, 0, 1) for w in (wg, wu, wd))
+        g_full = Q.qlinear(x, 0, gq, gs)[0]
+        u_full = Q.qlinear(x, 0, uq, us)[0]
+        hq_want, hs_want, _ = Q.silu_mul_quantize(g_full, u_full, 0)
+        y_want = Q.epilogue(Q.gemm_s8s8s32(hq_want, dq), hs_want, ds, None, 0)
+        ilo, ihi = shard_bounds(I, world, rank)
+        hlo, hhi = shard_bounds(H, world, rank)
+        bf = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.bfloat16)     # noqa: E731
+        nb = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)                          # noqa: E731
+
+        class Stub(ColumnShardedGatedMLP):
+            def _gate_up(self, xt):
+                return bf(g_full[:, ilo:ihi]), bf(u_full[:, ilo:ihi])
+
+            def _local_amax(self, g, u):
+                return torch.from_numpy(Q.row_amax_bits(Q.silu_mul(nb(g), nb(u), 0), 0).view(np.int32).copy())
+
+            def _encode(self, g, u, amax_bits):
+                qq, ss = Q.quantize_rows_with_amax(Q.silu_mul(nb(g), nb(u), 0), 0, amax_bits.numpy().view(np.uint32))
+                return QTensor(torch.from_numpy(qq), torch.from_numpy(ss), 1, torch.bfloat16, torch.Size(qq.shape))
+
+            def _down(self, stacked, scale, dtype):
+                G, Mm, kps = stacked.shape
+                codes = stacked.permute(1, 0, 2).reshape(Mm, G * kps).numpy()            # what the slab walk computes: the row-major product
+                return bf(Q.epilogue(Q.gemm_s8s8s32(codes, dq[hlo:hhi]), scale.numpy(), ds[hlo:hhi], None, 0))
+
+        m = Stub.__new__(Stub)
+        torch.nn.Module.__init__(m)
+        m.gate_up = m.down = None
+        m.hidden, m.intermediate, m.group, m.native, m.world, m.rank = H, I, None, None, world, rank
+        y = m(bf(x))
+        stacked, scale = m.hidden_codes(bf(x))
+        ok = tuple(y.shape) == (M, H) and torch.equal(y.contiguous().view(torch.int16), bf(y_want).view(torch.int16))
+        ok = ok and tuple(stacked.shape) == (world, M, I // world) and np.array_equal(stacked.permute(1, 0, 2).reshape(M, I).numpy(), hq_want)
+        nan = np.isnan(hs_want)
+        ok = ok and np.array_equal(np.isnan(scale.numpy()), nan) and np.array_equal(scale.numpy()[~nan].view(np.uint32), hs_want[~nan].view(np.uint32)) and bool(nan[1])
+        y3 = m(bf(x).reshape(2, M // 2, H))
+        ok = ok and tuple(y3.shape) == (2, M // 2, H)
+        q.put((rank, bool(ok)))
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,H,I", [(12, 64, 96), (6, 40, 128)])
+def test_column_sharded_gated_mlp_forward_world2(M, H, I):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cgm_worker, args=(r, world, port, M, H, I, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,226 @@
+"""-m gpu: the int8-code exchange of the column-sharded gated MLP (BASELINE config 5, gate/up -> down both column-sharded): the two halves of K1s
+(pq_silu_mul_rowamax, pq_silu_mul_quant_rowwise_amax), the GEMM on stacked code blocks (pq_qlinear_s8_kslabs) and ColumnShardedGatedMLP — G ranks
+played offline on one GPU (as test_llama70b_row_sharded_real_shapes does for the row-sharded pairing), against the C / numpy oracle and against the
+unsharded GatedMLP, bit for bit; a 1-rank RCCL communicator under hipGraph capture.  Real ranks: tests/rccl_rank_worker.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import qspec_numpy as Q
+from tests.gpu_util import TD, bits, same, to_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pq():
+    import protoquant_amd
+    from protoquant_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return protoquant_amd
+
+
+def _split(n, parts):
+    q, r = divmod(n, parts)
+    out, lo = [], 0
+    for i in range(parts):
+        hi = lo + q + (1 if i < r else 0)
+        out.append((lo, hi)); lo = hi
+    return out
+
+
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,parts", [(64, 4096, 8), (37, 3584, 1), (5, 1000, 3), (130, 11008, 8), (3, 77, 2), (9, 28672, 8), (16, 40000, 2)])
+def test_split_silu_quant_equals_the_fused_kernel_and_the_oracle(pq, code, rows, cols, parts):
+    """column blocks: local amax per block (vector and generic layouts, ragged and unaligned widths), integer max over the blocks, encode per block == the oracle's
+    S1-S6 on the whole row and == the one-pass kernel; special values (NaN, Inf, zero rows) propagate exactly as in K1s."""
+    rng = np.random.default_rng(rows * 7 + cols + code)
+    g = (rng.standard_normal((rows, cols)) * 3).astype(np.float32)
+    u = rng.standard_normal((rows, cols)).astype(np.float32)
+    if rows >= 5:
+        g[1, cols // 2] = np.nan; u[2, 3] = np.inf; g[3, :] = 0; u[4, :] = 0; g[0, 0] = 200.0; g[0, 1] = -200.0
+    gs, us = Q.from_f32(g, code), Q.from_f32(u, code)
+    want_q, want_s, _ = C.silu_mul_quant_rowwise(gs, us, code, want_h=False)
+    gt, ut = to_gpu(gs, code), to_gpu(us, code)
+    blocks = _split(cols, parts)
+    am = [pq.silu_mul_rowamax(gt[:, a:b], ut[:, a:b]) for a, b in blocks]
+    for (a, b), t in zip(blocks, am):           # each block's amax is the oracle's (NaN as a class: above +Inf)
+        want = Q.row_amax_bits(Q.silu_mul(gs[:, a:b], us[:, a:b], code), code)
+        got = t.cpu().numpy().view(np.uint32)
+        nan = want > 0x7F800000
+        assert np.array_equal(got > 0x7F800000, nan) and np.array_equal(got[~nan], want[~nan])
+    glob = torch.stack(am).max(dim=0).values
+    q = torch.empty((rows, cols), dtype=torch.int8, device="cuda")
+    scales = []
+    for a, b in blocks:
+        scales.append(pq.silu_mul_quantize_with_amax(gt[:, a:b], ut[:, a:b], glob, out=q[:, a:b]).scale)
+    same(q, want_q, "codes of the blocks")
+    for s in scales:
+        same(s, want_s, "row scales")
+    one = pq.silu_mul_quantize(gt, ut)
+    assert torch.equal(one.int_data, q) and torch.equal(one.scale.view(torch.int32), scales[0].view(torch.int32))
+
+
+@pytest.mark.parametrize("M,N,K,G,in_place", [(4096, 1024, 28672, 8, True), (1024, 1024, 8192, 8, True), (2048, 512, 4096, 4, True), (700, 1000, 1024, 2, True),
+                                             (256, 4096, 2048, 2, True), (4096, 4096, 4096, 4, False), (2048, 4096, 11008, 2, False), (16, 1024, 8192, 8, False), (37, 50, 384, 3, False),
+                                             (300, 640, 960, 5, False)])
+def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
+    """pq_qlinear_s8_kslabs == pq_qlinear_s8 on the row-major codes, bit for bit: the ring tiles (128 x 128, 64 x 128, 64 x 64) walk the slabs in place (no
+    workspace); every other dispatch — 256-wide tiles (plain and fused split-K), the weight-streaming kernel, the generic kernel with K / G not a multiple of 128 — takes the layout pass.  All three output dtypes, with bias."""
+    from protoquant_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    xq = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    wq = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).cuda()
+    xs = (torch.rand(M, generator=g) * 0.01 + 1e-4).cuda()
+    ws = (torch.rand(N, generator=g) * 0.01 + 1e-4).cuda()
+    kps = K // G
+    stacked = xq.reshape(M, G, kps).permute(1, 0, 2).contiguous()
+    assert (_lib.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps) == 0) == in_place
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        bias = (torch.randn(N, generator=g) * 0.1).to(dt).cuda()
+        for b in (None, bias):
+            want = pq.qlinear_s8(xq, xs, wq, ws, b, dt)
+            got = pq.qlinear_s8_kslabs(stacked, xs, wq, ws, b, dt)
+            assert torch.equal(got.view(torch.int32 if dt == torch.float32 else torch.int16), want.view(torch.int32 if dt == torch.float32 else torch.int16)), (dt, b is not None)
+    if M * N * K <= 300 * 640 * 960:            # small enough for the numpy oracle
+        acc = Q.gemm_s8s8s32(xq.cpu().numpy(), wq.cpu().numpy())
+        same(pq.qlinear_s8_kslabs(stacked, xs, wq, ws, None, torch.bfloat16), Q.epilogue(acc, xs.cpu().numpy(), ws.cpu().numpy(), None, 0), "vs oracle")
+    try:                                        # the switch: the layout pass everywhere, same bits
+        _lib.set_option("PQ_NO_KSLABS", "1")
+        assert _lib.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps) > 0
+        assert torch.equal(pq.qlinear_s8_kslabs(stacked, xs, wq, ws, None, torch.bfloat16).view(torch.int16), pq.qlinear_s8(xq, xs, wq, ws, None, torch.bfloat16).view(torch.int16))
+    finally:
+        _lib.set_option("PQ_NO_KSLABS", "")
+
+
+def test_kslabs_argument_validation(pq):
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    a = torch.zeros((2, 64, 128), dtype=torch.int8, device="cuda")
+    w = torch.zeros((32, 256), dtype=torch.int8, device="cuda")
+    s1, s2 = torch.ones(64, device="cuda"), torch.ones(32, device="cuda")
+    y = torch.empty((64, 32), dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    # K not a multiple of k_per_slab; slabs that overlap; missing workspace on a shape that needs the layout pass
+    assert L.pq_qlinear_s8_kslabs(a.data_ptr(), 128, 64 * 128, 100, s1.data_ptr(), w.data_ptr(), 256, s2.data_ptr(), None, y.data_ptr(), 32, 0, 64, 32, 256, None, 0, st) == 1
+    assert L.pq_qlinear_s8_kslabs(a.data_ptr(), 128, 100, 128, s1.data_ptr(), w.data_ptr(), 256, s2.data_ptr(), None, y.data_ptr(), 32, 0, 64, 32, 256, None, 0, st) == 1
+    need = L.pq_qlinear_kslabs_workspace_bytes(64, 32, 256, 128)
+    assert need >= 64 * 256
+    assert L.pq_qlinear_s8_kslabs(a.data_ptr(), 128, 64 * 128, 128, s1.data_ptr(), w.data_ptr(), 256, s2.data_ptr(), None, y.data_ptr(), 32, 0, 64, 32, 256, None, 0, st) == 5
+    with pytest.raises(ValueError):
+        pq.qlinear_s8_kslabs(a.permute(1, 0, 2), s1, w, s2, None, torch.bfloat16)          # not contiguous [G, M, K/G]
+    with pytest.raises(ValueError):
+        pq.silu_mul_quantize_with_amax(torch.zeros(4, 8, device="cuda", dtype=torch.bfloat16), torch.zeros(4, 8, device="cuda", dtype=torch.bfloat16),
+                                       torch.zeros(4, device="cuda"))                        # amax must be int32 bit patterns
+
+
+def _linears(H, I, seed, bias=False, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for (o, i) in ((I, H), (I, H), (H, I)):
+        lin = torch.nn.Linear(i, o, bias=bias, device="cuda", dtype=dtype)
+        with torch.no_grad():
+            lin.weight.copy_((torch.randn(o, i, generator=g) * 0.03).to(dtype))
+            if bias:
+                lin.bias.copy_((torch.randn(o, generator=g) * 0.05).to(dtype))
+        out.append(lin)
+    return out
+
+
+def _play_ranks(pq, lins, x, G, ranks=None):
+    """every rank of a G-rank ColumnShardedGatedMLP on this one GPU: the device steps are the module's own, the three collectives are replaced by their
+    definitions (integer max over the ranks, stacking of the code blocks, concatenation of the output shards).  Returns (stacked codes, scales, {rank: y shard})."""
+    mods = [pq.ColumnShardedGatedMLP.from_linears(*lins, world=G, rank=r) for r in range(G)]
+    x2 = x.reshape(-1, x.shape[-1])
+    gu = [m._gate_up(x2) for m in mods]
+    glob = torch.stack([m._local_amax(g_, u_) for m, (g_, u_) in zip(mods, gu)]).max(dim=0).values
+    hq = [m._encode(g_, u_, glob) for m, (g_, u_) in zip(mods, gu)]
+    stacked = torch.stack([h.int_data for h in hq]).contiguous()
+    for h in hq[1:]:
+        assert torch.equal(h.scale.view(torch.int32), hq[0].scale.view(torch.int32))
+    ys = {r: mods[r]._down(stacked, hq[r].scale, x.dtype) for r in (ranks if ranks is not None else range(G))}
+    return stacked, hq[0].scale, ys
+
+
+@pytest.mark.parametrize("M,H,I,G,bias,dtype", [(300, 512, 1024, 2, True, torch.bfloat16), (129, 256, 1536, 8, False, torch.float16), (64, 384, 768, 3, True, torch.bfloat16),
+                                                (1000, 1024, 4096, 4, False, torch.bfloat16)])
+def test_column_sharded_gated_mlp_equals_the_unsharded_block(pq, M, H, I, G, bias, dtype):
+    """G ranks played offline: the int8 codes and row scales of the intermediate, and the block output, are the unsharded GatedMLP's, bit for bit; and the
+    unsharded block is the oracle chain's."""
+    lins = _linears(H, I, M + H + I, bias, dtype)
+    x = (torch.randn(M, H, generator=torch.Generator().manual_seed(M)) * 1.5).to(dtype).cuda()
+    ref = pq.GatedMLP.from_linears(*lins)
+    g, u = ref.gate_up(x)
+    hq_ref = pq.silu_mul_quantize(g, u)
+    y_ref = ref(x)
+    stacked, scale, ys = _play_ranks(pq, lins, x, G)
+    assert torch.equal(stacked.permute(1, 0, 2).reshape(M, I), hq_ref.int_data) and torch.equal(scale.view(torch.int32), hq_ref.scale.view(torch.int32))
+    y = torch.cat([ys[r] for r in range(G)], dim=1)
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+    # ... and the unsharded block against the oracle chain (so the sharded one is pinned to the oracle as well)
+    code = 0 if dtype == torch.bfloat16 else 1
+    wq = [C.quant_rowwise(bits(l.weight), code) for l in lins]
+    bb = [bits(l.bias) if bias else None for l in lins]
+    xq, xs = C.quant_rowwise(bits(x), code)
+    sq, ss, _ = C.silu_mul_quant_rowwise(C.qlinear_s8(xq, xs, *wq[0], bb[0], code), C.qlinear_s8(xq, xs, *wq[1], bb[1], code), code)
+    same(y, C.qlinear_s8(sq, ss, *wq[2], bb[2], code), "sharded block vs oracle chain")
+
+
+def test_column_sharded_gated_mlp_llama70b_real_shapes(pq):
+    """BASELINE config 5 at its real shapes (M = 4096 tokens, hidden 8192, intermediate 28672, 8 ranks): all eight ranks' gate/up shards and code blocks, two ranks'
+    down shards (4096 x 1024 x 28672 on the stacked blocks — the ring tile walking the slabs in place) against the unsharded block."""
+    M, H, I, G = 4096, 8192, 28672, 8
+    lins = _linears(H, I, 70, False)
+    x = torch.randn(M, H, generator=torch.Generator().manual_seed(70)).to(torch.bfloat16).cuda()
+    ref = pq.GatedMLP.from_linears(*lins)
+    g, u = ref.gate_up(x)
+    hq_ref = pq.silu_mul_quantize(g, u)
+    y_ref = ref.down(hq_ref)
+    del g, u
+    stacked, scale, ys = _play_ranks(pq, lins, x, G, ranks=(0, 5))
+    assert torch.equal(scale.view(torch.int32), hq_ref.scale.view(torch.int32))
+    assert torch.equal(stacked.permute(1, 0, 2).reshape(M, I), hq_ref.int_data)
+    for r, y in ys.items():
+        assert torch.equal(y.view(torch.int16), y_ref[:, r * (H // G):(r + 1) * (H // G)].contiguous().view(torch.int16)), r
+
+
+def test_column_sharded_gated_mlp_world1_rccl_under_capture(pq):
+    """a 1-rank RCCL communicator: forward() through libpq_rccl.so (all-reduce max, byte all-gather, output gather) eagerly and replayed from a hipGraph."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29549")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        gather = pq.RcclColumnGather()
+        lins = _linears(512, 1024, 5, True)
+        x = torch.randn(3, 100, 512, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+        y_ref = pq.GatedMLP.from_linears(*lins)(x)
+        m = pq.ColumnShardedGatedMLP.from_linears(*lins, native=gather)
+        y = m(x)
+        assert y.shape == y_ref.shape and torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+        m2 = pq.ColumnShardedGatedMLP.from_linears(*lins)          # torch.distributed collectives (world 1: no-ops)
+        assert torch.equal(m2(x).view(torch.int16), y_ref.view(torch.int16))
+        out = torch.empty_like(y_ref)
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(x)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                out.copy_(m(x))
+            for _ in range(3):
+                out.zero_(); gr.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), y_ref.view(torch.int16))
+        gather.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    with pytest.raises(ValueError):
+        pq.ColumnShardedGatedMLP.from_linears(*_linears(256, 1000, 3), world=3, rank=0)       # 1000 % 3 != 0
