@@ -547,6 +547,42 @@ def run_llama70b_shard(args):
         del rl
     except Exception as e:      # an extra figure must never lose the main line
         print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
+    # Extra key — the INT8-CODE EXCHANGE between gate/up and down (ColumnShardedGatedMLP: everything stays column-sharded, as north_star asks): the rank computes
+    # silu*mul on ITS 3584 intermediate channels only — row amax of the local block, [all-reduce(max) of 4096 32-bit patterns: not run on one GPU], encode against the
+    # global amax — and the down shard's GEMM walks the all-gathered int8 blocks [8, 4096, 3584] in place.  Against the plain composition above, the re-quantisation of
+    # the gathered 4096 x 28672 activation on every rank (and the gather of bf16 gate AND up: 4 bytes per intermediate element instead of 1) is gone.
+    int8x = None
+    try:
+        from protoquant_amd.qtensor import silu_mul_quantize_with_amax, silu_mul_rowamax
+        ig = I // G
+        stacked = torch.randint(-127, 128, (G, M, ig), device=dev, dtype=torch.int8)          # stands for the all-gathered code blocks
+        stacked_scale = torch.rand(M, device=dev) * 1e-2 + 1e-4
+
+        def fwd_int8():
+            for l in range(L):
+                qkv, o, gu, down = layers[l % NL]
+                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
+                o(x_h)
+                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(ig, dim=-1)
+                am = silu_mul_rowamax(g_, u_)
+                silu_mul_quantize_with_amax(g_, u_, am, out=stacked[0])
+                pq.qlinear_s8_kslabs(stacked, stacked_scale, down.wq, down.ws, None, torch.bfloat16)
+            return head(x_h)
+        fwd_int8(); torch.cuda.synchronize()
+        ti = []
+        for _ in range(3):
+            t0 = time.perf_counter(); fwd_int8(); torch.cuda.synchronize()
+            ti.append(time.perf_counter() - t0)
+        di = sorted(ti)[1]
+        XG = 153e9
+        hop_bf16 = 2 * (2.0 * M * ig) / XG + 2 * 2 * (2.0 * M * I * 2) / 5e12       # gather of the bf16 gate and up shards (one link per peer, all links at once) + their layout passes
+        hop_int8 = (4.0 * M) / XG + (1.0 * M * ig) / XG                             # all-reduce of M amax patterns (latency-bound in practice) + gather of the int8 blocks; no layout pass
+        int8x = {"ms_per_step": round(di * 1e3, 3), "value": round(ops / di / 1e12, 2), "unit": "TOPS", "us_per_layer": round((di - 0) / L * 1e6, 1),
+                 "what": "per layer: rmsnorm x2, qkv shard, K1 + o shard, gate+up shard, silu*mul row amax + encode on the LOCAL 3584 channels, down shard on the stacked int8 blocks (slabs walked in place)",
+                 "modelled_gate_up_to_down_hop_us": {"bf16_gather_of_gate_and_up_plus_layout": round(hop_bf16 * 1e6, 1), "int8_code_exchange": round(hop_int8 * 1e6, 1),
+                                                     "model": "bytes over one direct xGMI link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s; NOT measured"}}
+    except Exception as e:      # an extra figure must never lose the main line
+        print(f"[bench] int8-code exchange leg failed: {e}", file=sys.stderr)
     # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (all NL weight sets in turn: HBM-fed like the step),
     # with its share of the layer and — for the GEMMs —
     # its fraction of the int8 peak: the per-shape account of the distance to 0.50
@@ -571,6 +607,15 @@ def run_llama70b_shard(args):
                  ("fused gate+up shard", (M, n_gu, H), lambda l: layers[l][2](qn), 1),
                  ("K1 of down's input (the GATHERED silu(g)*u, 4096 x 28672)", None, lambda l: pq.quantize(x_i), 1),
                  ("down shard", (M, n_down, I), lambda l: layers[l][3](qi), 1)]
+        # the int8-code exchange's three kernels (reported beside the account, not summed into it)
+        extra_items = []
+        if int8x is not None:
+            gu_out = layers[0][2](qn)
+            g0, u0 = gu_out.split(I // G, dim=-1)
+            am0 = silu_mul_rowamax(g0, u0)
+            extra_items = [("silu*mul row amax, local 4096 x 3584 (int8-code exchange)", None, lambda l: silu_mul_rowamax(g0, u0), 1),
+                           ("silu*mul encode against the global amax, local 4096 x 3584", None, lambda l: silu_mul_quantize_with_amax(g0, u0, am0, out=stacked[0]), 1),
+                           ("down shard on stacked int8 blocks [8, 4096, 3584]", (M, n_down, I), lambda l: pq.qlinear_s8_kslabs(stacked, stacked_scale, layers[l][3].wq, layers[l][3].ws, None, torch.bfloat16), 1)]
         per_shape, tot = [], 0.0
         for name, shp, fn, mult in items:
             us = ev_graph(lambda: [fn(l) for l in range(NL)], 2) / NL
@@ -584,6 +629,30 @@ def run_llama70b_shard(args):
         for d in per_shape:
             d["share_of_layer"] = round(d["us"] * d["per_layer"] / tot, 3)
         per_shape.append({"sum_per_layer_us": round(tot, 1), "step_per_layer_us": round(dt / L * 1e6, 1)})
+        # one layer of each composition replayed gap-free from a hipGraph over the NL weight sets (host-independent; the eager steps above carry Python's launch overhead)
+        def layer_plain(l):
+            qkv, o, gu, down = layers[l]
+            qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); o(x_h); gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); down(x_i)
+        lg = {"column_sharded_bf16_gather": round(ev_graph(lambda: [layer_plain(l) for l in range(NL)], 2) / NL, 1)}
+        if int8x is not None:
+            def layer_int8(l):
+                qkv, o, gu, down = layers[l]
+                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); o(x_h)
+                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(I // G, dim=-1)
+                silu_mul_quantize_with_amax(g_, u_, silu_mul_rowamax(g_, u_), out=stacked[0])
+                pq.qlinear_s8_kslabs(stacked, stacked_scale, down.wq, down.ws, None, torch.bfloat16)
+            lg["int8_code_exchange"] = round(ev_graph(lambda: [layer_int8(l) for l in range(NL)], 2) / NL, 1)
+            int8x["us_per_layer_graph"] = lg["int8_code_exchange"]
+        per_shape.append({"layer_us_from_hipgraph": lg})
+        if extra_items:
+            ex = []
+            for name, shp, fn, mult in extra_items:
+                us = ev_graph(lambda: [fn(l) for l in range(NL)], 2) / NL
+                d = {"kernel": name, "us": round(us, 1)}
+                if shp is not None:
+                    d["frac_of_int8_peak"] = round(2.0 * shp[0] * shp[1] * shp[2] / us / 1e6 / PEAK_INT8_TOPS, 3)
+                ex.append(d)
+            int8x["kernels"] = ex
     except Exception as e:
         print(f"[bench] per-shape leg failed: {e}", file=sys.stderr)
     # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
@@ -595,7 +664,7 @@ def run_llama70b_shard(args):
                       "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
                                              f"4096x{n_o}x8192 (o), 4096x{n_gu}x8192 (fused gate+up), 4096x{n_down}x28672 (down), 4096x{n_head}x8192 (lm_head) (BASELINE configs[4])",
                                  "int8_ops_per_rank": ops, "gathered_bytes_per_pass": gathered,
-                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing, "per_shape": per_shape,
+                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing, "int8_code_exchange": int8x, "per_shape": per_shape,
                                  "model": "all-gather after dequant of every linear's bf16 output; a rank receives 7/8 of it over 7 xGMI links x 153 GB/s (fully connected, direct); NOT measured"},
                       "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                                    "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
