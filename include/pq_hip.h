@@ -132,7 +132,13 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
  * PQ_FSK_SYMMETRIC=1 opts into the symmetric exchange for 2 / 4 slices (each workgroup keeps a part of the tile and
  * WAITS for its partners' contributions: 2-5 % faster): the caller then guarantees that every workgroup of the launch
  * can be resident at once — no second fused split-K GEMM in flight on another stream, no CU mask — and the planner
- * additionally refuses it when tiles x slices exceeds the device's CU count. */
+ * additionally refuses it when tiles x slices exceeds the device's CU count.  PQ_FSK_COOP=1 launches those symmetric kernels
+ * COOPERATIVELY instead (hipLaunchCooperativeKernel: the runtime guarantees co-residency or refuses, then the ticket form runs) — correct, also under
+ * hipGraph capture, but measured 21-24 us slower per launch than the ticket form on ROCm 7.2 (profiles/r05_ab_fsk_coop.txt): opt-in.
+ * Output rows that are not 16-byte aligned (an odd ldy, e.g. a 50257-wide vocabulary): the staged epilogue stores its 16-byte pieces at element-aligned addresses,
+ * which needs the queue's unaligned-access mode (SH_MEM_CONFIG alignment mode "unaligned" — the default of ROCm compute queues on gfx9, but a platform setting, not an
+ * architectural guarantee: some virtual functions and debug configurations run strict).  On such a platform set PQ_EPI_ANY_ALIGN=0 (environment or pq_set_option): those
+ * rows then take the slower guarded direct stores; everything else is unaffected. */
 int32_t pq_qlinear_s8(const int8_t* a, int64_t lda, const float* a_scale,
                       const int8_t* b, int64_t ldb, const float* b_scale,
                       const void* bias, void* y, int64_t ldy, int32_t out_dtype,

@@ -14,6 +14,7 @@ struct EpiArgs {
     void* y;                // [M, ldy]
     int64_t ldy;
     int32_t flags;          // EPI_* bits; 0 = QSPEC as written: (f32(acc) * a_scale[row]) * b_scale[col] (+ bias[col])
+    int32_t nxcd = 8;          // XCDs of the device the launch goes to (the C-ABI entry points set it from hipDeviceAttributeNumberOfXccs): the tile remaps group tiles per L2
     int32_t y_any_align = 0;   // 1: the staged epilogue may store its 16-byte pieces at element-aligned addresses (odd leading dimensions, e.g. a 50257-wide vocabulary)
 };
 // rows of y fit the staged epilogue's 16-byte write-through stores: 16-byte aligned rows, or (y_any_align) any element-aligned address — gfx950 compute queues run

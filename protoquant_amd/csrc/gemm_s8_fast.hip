@@ -139,7 +139,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
         const int p = (int)blockIdx.x / FSK, qg = ntiles_all / NGX, rg = ntiles_all % NGX, grp = p % NGX, idx = p / NGX;
         t = (grp < rg ? grp * (qg + 1) : rg * (qg + 1) + (grp - rg) * qg) + idx;
     } else {
-        t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all);
+        t = xcd_remap((int)blockIdx.x - kslice * ntiles_all, ntiles_all, epi.nxcd);
     }
     constexpr int GM = 4;
     const int band = t / (GM * tiles_n);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_p3_persist(const int8_t* __res
     // coordinates of output tile `tix` and the per-lane source offsets of this wave's DMA pieces (as in gemm_s8_sp256)
     auto locate = [&](int tix, Src& o) {
         const int lane = lane_now();
-        const int t = xcd_remap(tix, ntiles);
+        const int t = xcd_remap(tix, ntiles, epi.nxcd);
         constexpr int GM = 4;
         const int band = t / (GM * tiles_n);
         const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;
@@ -997,8 +997,24 @@ bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
     if (hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st) != hipSuccess) return false;   // tickets and ready counts / flags
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
-    // the SYMMETRIC exchanges wait for partner workgroups and are taken only on the caller's promise (PQ_FSK_SYMMETRIC=1: pq_hip.h); the default
-    // ticket form never waits for a workgroup that may not be running
+    // the SYMMETRIC exchanges WAIT for partner workgroups: they need every workgroup of the launch resident at once.  A COOPERATIVE launch (round 5) is the runtime's own
+    // guarantee of exactly that — hipLaunchCooperativeKernel either places the whole grid together (and serialises cooperative launches of the device against each other) or
+    // returns an error — so with PQ_FSK_COOP=1 the symmetric kernels go out that way, and any error (grid too large for the CUs this queue may use, a capture
+    // that does not take cooperative nodes, an old runtime) falls through to the ticket form, which never waits for a workgroup that may not be running.
+    // MEASURED (profiles/r05_ab_fsk_coop.txt): it works, eagerly and under hipGraph capture, bit-identical — and costs 21-24 us per launch (the runtime's cooperative
+    // queue hand-off): 2048 x 4096 x 11008 97.9 us against 75.9 ticket / 74.0 symmetric, 4096 x 1024 x 28672 119.0 against 99.5 / 94.0.  The safe route to the
+    // symmetric exchange costs ten times what the exchange saves: OFF by default.  PQ_FSK_SYMMETRIC=1 remains the caller's-promise route (plain launch).
+    if ((kslices == 2 || kslices == 4) && opt().fsk_coop && !opt().fsk_symmetric) {
+        int M_ = (int)M, N_ = (int)N, K_ = (int)K, tm_ = tiles_m, tn_ = tiles_n, zero = 0, ks_ = kslices;
+        int64_t lda_ = lda, ldb_ = ldb;
+        EpiArgs epi_ = epi;
+        unsigned long long* ws_ = ws;
+        void* args[] = {(void*)&A, (void*)&lda_, (void*)&B, (void*)&ldb_, (void*)&epi_, (void*)&M_, (void*)&N_, (void*)&K_, (void*)&tm_, (void*)&tn_, (void*)&zero, (void*)&ws_, (void*)&ks_};
+        const void* fn = kslices == 2 ? reinterpret_cast<const void*>(&gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2>)
+                                      : reinterpret_cast<const void*>(&gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4>);
+        if (hipLaunchCooperativeKernel(fn, grid, block, args, 0, st) == hipSuccess) return true;
+        (void)hipGetLastError();      // not placed: the ticket form below
+    }
     const bool sym = opt().fsk_symmetric;
     if (kslices == 2 && sym)
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, ws, 2);
@@ -1113,7 +1129,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     const int w = wave & 3;                                            // index inside the role
     const int wp = w >> 1, wq = w & 1;
 
-    int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+    int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n, epi.nxcd);
     constexpr int GM = 8;
     const int band = t / (GM * tiles_n);
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;

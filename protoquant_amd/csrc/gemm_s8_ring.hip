@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
     // tile assignment: XCD remap (blocks of one XCD get a contiguous run of tiles), then bands of up to 8 m-tiles with m fastest inside the band (as gemm_s8_ring128): the
     // tiles that stream one weight panel are neighbours on one XCD — the panel comes from HBM once per XCD, the others hit its L2 — and an XCD's 32 tiles touch 8 activation
     // + 4 weight panels instead of 32 + 1
-    const int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+    const int t = xcd_remap((int)blockIdx.x, tiles_m * tiles_n, epi.nxcd);
     constexpr int GM = 8;
     const int band = t / (GM * tiles_n);
     const int gm = (tiles_m - band * GM) < GM ? (tiles_m - band * GM) : GM;

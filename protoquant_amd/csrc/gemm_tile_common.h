@@ -45,9 +45,12 @@ __device__ __forceinline__ void glds16_vaddr(const void* src, uint32_t lds_addr)
                  :: "v"(src), "s"(lds_addr) : "memory");
 }
 
-// XCD-aware bijective remap: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+// XCD-aware bijective remap: workgroups are dealt to the XCDs round-robin, so blocks that share an XCD (equal bid % nx) get a contiguous run of tiles.  nx = the XCDs of
+// the device (8 on a whole MI355X; a partitioned device has fewer — 1 makes this the identity); any nx >= 1 gives a bijection.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg, int nx = 8) {
+    int q, r, xcd, idx;
+    if (nx == 8) { q = nwg >> 3; r = nwg & 7; xcd = bid & 7; idx = bid >> 3; }
+    else { q = nwg / nx; r = nwg - q * nx; idx = bid / nx; xcd = bid - idx * nx; }
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 

@@ -77,7 +77,7 @@ thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by
 thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_NO_KSLABS", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FSK_COOP", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_NO_KSLABS", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE", "PQ_SKINNY_KS"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
@@ -89,6 +89,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_FSK")) o.fsk = set ? iv : -1;
     else if (!strcmp(name, "PQ_FSK_SYMMETRIC")) o.fsk_symmetric = set && *value == '1';
     else if (!strcmp(name, "PQ_FSK_FENCED")) o.fsk_fenced = set && *value == '1';
+    else if (!strcmp(name, "PQ_FSK_COOP")) o.fsk_coop = set && *value == '1';
     else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_NO_MIDM")) o.no_midm = set;
     else if (!strcmp(name, "PQ_NO_KSLABS")) o.no_kslabs = set;
@@ -158,6 +159,19 @@ int device_cus() {
     }
     return n;
 }
+// XCDs (L2 domains) of the current device for the tile remaps (hipDeviceAttributeNumberOfXccs, cached; a partitioned device reports fewer); with PQ_FAKE_CUS: one per 32 CUs
+int device_xcds() {
+    if (options().fake_cus > 0) return options().fake_cus >= 32 ? options().fake_cus / 32 : 1;
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 8; }
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n <= 0 || n > 64) { (void)hipGetLastError(); n = 8; }
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 Variant forced_variant() { return static_cast<Variant>(options().variant); }
 
 struct Range {      // one C-ABI call: pins the option snapshot (CallScope) and, with PQ_ROCTX, a roctx range (host side: it brackets the asynchronous launches)
@@ -190,22 +204,23 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
     // blocks at ~3/4 of the per-CU rate (ingest-bound) — worth it when they keep everything in one round.
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
     const int64_t t128sq = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t cus = device_cus();          // one workgroup of these tiles per CU: every "fills the chip" threshold below is a share of the CUs THIS device reports (round 5; 256 on a whole MI355X)
     // even 128-row tiles fill at most half the chip: 128 x 128 tiles from a 4-deep DMA ring (gemm_s8_ring128; latency-bound
     // on operand ingest, ~2/3 of the 128 x 256 tile's rate per CU, but twice the blocks and no slab traffic).  Measured:
     // k/v 4096x1024x4096 31 -> 24 us, 70B q/o shard 47 (split-K) -> 40 us, 70B down shard 124 (split-K) -> 119 us.
-    if (t128 <= 128 && t128sq > t128) {
+    if (t128 <= cus / 2 && t128sq > t128) {
         // 64 < M <= 512 (gemm_s8_ring.hip): when the 128 x 128 ring tiles fill well under the chip, SMALLER tiles on every CU — the regime is bound by the L2 -> CU path
         // (profiles/r04_ablate_ring.txt), and a K split over workgroups costs more hand-over than it saves on launches this short (measured: profiles/r04_midm_fsk.txt).  Rounds of the 256 CUs x the measured time of one tile relative to the 128 x 128 ring tile (K = 4096: 14.0 / 13.4 / 9.2 us; profiles/r04_midm.txt);
         // PQ_NO_MIDM=1 restores the round-3 dispatch.
         if (!options().no_midm && options().force_splitk <= 1 && options().fsk <= 1) {      // (a forced slice count — experiments, tests — means the split-K forms)
-            auto rounds = [](int64_t tiles) { return (double)((tiles + 255) / 256); };
+            auto rounds = [cus](int64_t tiles) { return (double)((tiles + cus - 1) / cus); };
             const double c128 = rounds(t128sq) * 1.00, c64x128 = rounds(((M + 63) / 64) * ((N + 127) / 128)) * 0.95, c64x64 = rounds(((M + 63) / 64) * ((N + 63) / 64)) * 0.66;
             if (c64x64 < c128 && c64x64 <= c64x128) return V_RING64X64;
             if (c64x128 < c128) return V_RING64X128;
         }
         return V_RING128;
     }
-    if (t256 <= 160 && t128 > t256 && t128 <= 256) return V_SP128_16;
+    if (t256 <= cus * 5 / 8 && t128 > t256 && t128 <= cus) return V_SP128_16;
     return V_SP256_16;
 }
 
@@ -232,20 +247,20 @@ constexpr double kHalfTileCost = 0.58, kSecondLaunchCost = 0.06;   // (round 2: 
 
 int tail_split_plan(int64_t M, int64_t N, int64_t* lead) {
     if (options().no_tailsplit) return 0;
-    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
-    if (tiles <= 256) return 0;
-    auto rounds = [](int64_t blocks) { return (double)((blocks + 255) / 256); };
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn, cus = device_cus();
+    if (tiles <= cus) return 0;
+    auto rounds = [cus](int64_t blocks) { return (double)((blocks + cus - 1) / cus); };
     double best = rounds(tiles) - 0.12;   // a split must save at least ~1/8 of a round to be worth a second launch
     int axis = 0;
     const int64_t hm = (M + 127) / 128;
     for (int64_t c = 1; c < tn; ++c) {    // trailing c tile columns, all rows, as 128-row tiles
-        if (hm * c > 512) break;
+        if (hm * c > 2 * cus) break;
         const double cost = rounds(tm * (tn - c)) + rounds(hm * c) * kHalfTileCost + kSecondLaunchCost;
         if (cost < best) { best = cost; axis = 1; *lead = (tn - c) * 256; }
     }
     for (int64_t r = 1; r < tm; ++r) {    // trailing r tile rows, all columns
         const int64_t tail_h = (M - (tm - r) * 256 + 127) / 128;
-        if (tail_h * tn > 512) break;
+        if (tail_h * tn > 2 * cus) break;
         const double cost = rounds((tm - r) * tn) + rounds(tail_h * tn) * kHalfTileCost + kSecondLaunchCost;
         if (cost < best) { best = cost; axis = 2; *lead = (tm - r) * 256; }
     }
@@ -453,6 +468,7 @@ int32_t pq_gemm_s8s8s32(const int8_t* a, int64_t lda, const int8_t* b, int64_t l
         return fail(PQ_ERR_BAD_ARG, "pq_gemm_s8s8s32: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldc=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldc);
     if (M == 0 || N == 0) return PQ_OK;
     pq::EpiArgs epi{nullptr, nullptr, nullptr, c, ldc, 0};
+    epi.nxcd = device_xcds();
     run_gemm_auto<pq::OUT_I32>(pick_variant(a, lda, b, ldb, M, N, K), a, lda, b, ldb, epi, M, N, K, static_cast<hipStream_t>(stream));
     return check_launch("pq_gemm_s8s8s32");
 }
@@ -466,14 +482,15 @@ static int splitk_plan(int64_t M, int64_t N, int64_t K, int* tm_out) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 255) / 256);
     // (round 3 split the quarter-filled 256 x 256 grid with a very long K — the Llama-70B `down` shard, 4096 x 1024 x 28672 — four ways here, 99 us against 128 for the
     // ring tile fed from HBM; since round 4 the ring tile's loaders rotate their K walk and it runs 102 us from HBM in ONE launch without a workspace: profiles/r04_rotation.txt)
-    const int tm = (t256 <= 160 && t128 > t256 && t128 <= 256) ? 128 : 256;
+    const int64_t cus = device_cus();
+    const int tm = (t256 <= cus * 5 / 8 && t128 > t256 && t128 <= cus) ? 128 : 256;
     const int64_t tiles = tm == 128 ? t128 : t256;
-    if (tiles > 128) return 1;
+    if (tiles > cus / 2) return 1;
     // the slab reduction costs ~15 us, and the single-pass alternative for these grids is the 128 x 128 ring tile: split-K
     // only pays when the grid fills at most a quarter of the chip and K is long (measured: 4096x512x8192 32 vs 35 us,
     // 1024x1024x8192 25 vs 34 us; at half-filled grids the ring tile wins at every K)
-    if (tiles > 64 || K < 8192) return 1;
-    int s = (tiles <= 32 && K >= 12288) ? 8 : 4;       // (128 x 4096 x 14336: 40 us with 4 slices, 28 us with 8)
+    if (tiles > cus / 4 || K < 8192) return 1;
+    int s = (tiles <= cus / 8 && K >= 12288) ? 8 : 4;       // (128 x 4096 x 14336: 40 us with 4 slices, 28 us with 8)
     while (s > 1 && (K % (128 * s) != 0 || K / s < 1024)) s >>= 1;
     *tm_out = tm;
     return s;
@@ -492,7 +509,7 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     // residency guard: the slices of a tile hand over inside the kernel, one workgroup per CU (160 KiB of LDS): plan it only when the whole grid fits the CUs
     // this device reports (a CU-masked or partitioned device reports fewer) — otherwise the two-pass split-K or the single-pass tile runs
     const int cus = device_cus();
-    if (t256 > 64 && t256 <= 128 && K >= 10240 && K % 256 == 0) return 2 * t256 <= cus ? 2 : 0;
+    if (t256 > cus / 4 && t256 <= cus / 2 && K >= 10240 && K % 256 == 0) return 2;          // (2 * t256 <= cus: the whole grid resident)
     // (the quarter-filled grid with a very long K — the Llama-70B `down` shard — ran four slices here in round 3: 91 us with the symmetric exchange, 104 in the
     // placement-independent ticket form; the 128 x 128 ring tile with the rotated K walk does 102 us in one pass with no workspace, so it is no longer planned.
     // PQ_FSK=4 still forces it.)
@@ -517,6 +534,7 @@ static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, cons
     Range range_("pq:qlinear_s8 (K3+K4)");
     pq::EpiArgs epi = epi_in;
     epi.y_any_align = options().epi_any_align ? 1 : 0;
+    epi.nxcd = device_xcds();
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // split-K needs the caller's workspace (pq_qlinear_workspace_bytes); without it the single-pass path runs.
@@ -583,12 +601,17 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
         (M > 0 && !a_scale) || (N > 0 && !b_scale))
         return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_t: bad arguments (M=%lld N=%lld K=%lld lda=%lld ldb=%lld ldyt=%lld)", (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, (long long)ldyt);
     if (M == 0 || N == 0) return PQ_OK;
+    // the workspace arguments are validated the same way on every path (the streaming path below does not use them; error behaviour must not depend on M)
+    if (workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "pq_qlinear_s8_t: workspace must be 16-byte aligned");
+    if (workspace == nullptr && workspace_bytes != 0) return fail(PQ_ERR_BAD_ARG, "pq_qlinear_s8_t: workspace_bytes without a workspace");
     {   // few tokens: the swapped form below would be a 16-column problem for the tile kernels (16 x 4096 x 4096: 23 us); the weight-streaming kernel computes the
         // product in its normal orientation and stores it transposed (5.8 us).  Same arithmetic as pq_qlinear_s8: same bits.
-        Range range_("pq:qlinear_s8_t (K3+K4, streaming)");
+        CallScope scope_;
         const Variant f = forced_variant();
         if ((f == V_AUTO || f == V_SKINNY) && pick_variant(a, lda, b, ldb, M, N, K) == V_SKINNY) {
+            Range range_("pq:qlinear_s8_t (K3+K4, streaming)");         // (named only where the streaming kernel really runs: marker traces)
             pq::EpiArgs e{a_scale, b_scale, bias, yt, ldyt, pq::EPI_STORE_T};
+            e.nxcd = device_xcds();
             hipStream_t st = static_cast<hipStream_t>(stream);
             switch (out_dtype) {
                 case PQ_BF16: run_gemm<PQ_BF16>(V_SKINNY, a, lda, b, ldb, e, M, N, K, st); break;
@@ -629,6 +652,7 @@ int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, 
         Range range_("pq:qlinear_s8_kslabs (K3+K4, slabs walked in place)");
         pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy, 0};
         epi.y_any_align = options().epi_any_align ? 1 : 0;
+        epi.nxcd = device_xcds();
         if (!pq::epi_flags_valid(epi.flags, epi.bias != nullptr)) abort();
         auto go = [&](auto oc) {
             constexpr int OUT = decltype(oc)::value;

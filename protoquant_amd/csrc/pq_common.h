@@ -31,6 +31,8 @@ struct Options {
     int midm_ct = 0;                 // PQ_MIDM_CT: K-tiles per rotation chunk of the mid-M ring tiles (0 = by rule, 1 = no rotation)
     bool no_kslabs = false;          // PQ_NO_KSLABS=1: pq_qlinear_s8_kslabs always takes the layout pass (never walks the slabs in place)
     bool no_midm = false;            // PQ_NO_MIDM=1: no 64-row ring tiles for 64 < M <= 512 (the round-3 dispatch)
+    bool fsk_coop = false;           // PQ_FSK_COOP=1: launch the symmetric fused split-K kernels COOPERATIVELY (co-residency guaranteed by the runtime, ticket form on error).
+                                     // Off by default: measured +21-24 us per launch on ROCm 7.2 / gfx950, against 2-5 us the symmetric exchange saves (profiles/r05_ab_fsk_coop.txt)
     bool fsk_fenced = false;         // PQ_FSK_FENCED=1: the ticket hand-over with the documented agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) as well
     int fake_cus = 0;                // PQ_FAKE_CUS=n: plan as if the device had n CUs (tests of the residency guard)
     bool skinny_stage = true;        // PQ_SKINNY_STAGE=0: the weight-streaming kernel with its activation fragments straight from L2 (rounds 1-3)

@@ -239,14 +239,27 @@ class _KPadded:
         kp = _round_k(K)
         if kp == K or K == 0:
             return self.wq, K
-        key = (self.wq.data_ptr(), self.wq._version, self.wq.device, tuple(self.wq.shape))
+        # keyed on the tensor OBJECT (held by a weak reference) and its version counter, not on its address: a weight replaced by a fresh tensor (module.to('cpu') ->
+        # load_state_dict -> .to('cuda'), load_state_dict(assign=True) after a del) starts again at version 0 and can be handed the very address the caching allocator
+        # just freed — an address-based key would then match and the GEMM would run on the OLD padded weight
+        import weakref
+        wq = self.wq
+        key = (wq._version, wq.device, tuple(wq.shape))
         c = self.__dict__.get("_wq_pad")
-        if c is None or c[0] != key:
-            w = self.wq.new_zeros((self.wq.shape[0], kp))
-            w[:, :K].copy_(self.wq)
-            c = (key, w)
+        if c is None or c[0] != key or c[2]() is not wq:
+            w = wq.new_zeros((wq.shape[0], kp))
+            w[:, :K].copy_(wq)
+            c = (key, w, weakref.ref(wq))
             self.__dict__["_wq_pad"] = c
         return c[1], kp
+
+    def __getstate__(self):
+        """pickling / torch.save of a module: the lazily built padded copy (and the weak reference that keys it) is a cache, not state"""
+        state = super().__getstate__()
+        if "_wq_pad" in state:
+            state = dict(state)
+            del state["_wq_pad"]
+        return state
 
     def _padded_forward(self, x, wq_pad, kp):
         """x: float [..., K] or a per-token QTensor; the GEMM runs over kp = round_up(K, 128) with zero tails on both operands."""

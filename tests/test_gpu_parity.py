@@ -280,6 +280,45 @@ def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
         pq_opt("PQ_FSK_SYMMETRIC", "1" if rep >= 3 else "")          # three launches in the ticket form, three in the symmetric form (S = 2 / 4; other S: ticket again)
         y = pq.qlinear_s8(*args)
         assert torch.equal(y.view(torch.uint8), y_def.view(torch.uint8)), f"fused split-K y (rep {rep})"
+    # round 5: the symmetric kernels under a COOPERATIVE launch (PQ_FSK_COOP=1: co-residency guaranteed by the runtime, ticket form if it refuses) — eagerly and
+    # captured into a hipGraph; measured slower than the ticket form (profiles/r05_ab_fsk_coop.txt), kept opt-in and bit-exact
+    pq_opt("PQ_FSK_SYMMETRIC", "")
+    pq_opt("PQ_FSK_COOP", "1")
+    for rep in range(2):
+        assert torch.equal(pq.qlinear_s8(*args).view(torch.uint8), y_def.view(torch.uint8)), f"cooperative fused split-K y (rep {rep})"
+    out = torch.empty_like(y_def)
+    s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        pq.qlinear_s8(*args, out=out)
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=s_):
+            pq.qlinear_s8(*args, out=out)
+        out.zero_(); g_.replay(); torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.uint8), y_def.view(torch.uint8)), "cooperative fused split-K under capture"
+
+
+@pytest.mark.parametrize("cus", [32, 64, 128, 256])
+def test_plans_made_for_fewer_cus_stay_bit_exact(pq, pq_opt, cus):
+    """PQ_FAKE_CUS (a partitioned / CU-masked device as the planner would see it, with its XCD count: one per 32 CUs in the tile remaps): every plan the smaller
+    device gets — other tile kinds, tail splits at other places, fused split-K on other grids — gives the bits of the default plan and of torch._int_mm."""
+    from protoquant_amd import _lib
+    seen = set()
+    for (M, N, K) in ((2048, 2816, 1024), (1024, 2048, 11264), (1000, 1100, 512), (512, 4096, 1024), (4096, 1280, 1024), (3000, 520, 640), (1024, 1024, 4096)):
+        g = torch.Generator().manual_seed(M + N + K)
+        a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8)
+        b = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+        xs, ws = torch.rand(M, generator=g).cuda() * 0.1, torch.rand(N, generator=g).cuda() * 0.01
+        ag, bg = a.cuda(), b.cuda()
+        pq_opt("PQ_FAKE_CUS", "")
+        y_def, acc_def = pq.qlinear_s8(ag, xs, bg, ws, None, torch.bfloat16), pq.int_mm(ag, bg)
+        assert torch.equal(acc_def.cpu(), torch._int_mm(a, b.t()))
+        pq_opt("PQ_FAKE_CUS", str(cus))
+        seen.add((_lib.lib().pq_gemm_variant_name(M, N, K, K, K), _lib.lib().pq_qlinear_workspace_bytes(M, N, K) > 0))
+        assert torch.equal(pq.qlinear_s8(ag, xs, bg, ws, None, torch.bfloat16).view(torch.int16), y_def.view(torch.int16)), (cus, M, N, K)
+        assert torch.equal(pq.int_mm(ag, bg), acc_def), (cus, M, N, K)
+        yt = pq.qlinear_s8_t(ag, xs, bg, ws, None, torch.bfloat16)
+        assert torch.equal(yt.t().contiguous().view(torch.int16), y_def.view(torch.int16)), (cus, "transposed", M, N, K)
+    assert len(seen) >= 3          # the shapes exercise several plans at every CU count
 
 
 @pytest.mark.parametrize("M", [1, 2, 7, 16, 17, 32, 33, 48, 64])

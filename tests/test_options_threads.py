@@ -82,3 +82,25 @@ def test_planner_refuses_fused_splitk_beyond_the_devices_cus(L):
     assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == _fsk_bytes(64, 4)              # forced: 64 tiles x 4 slices = 256 workgroups fit
     L.pq_set_option(b"PQ_FAKE_CUS", b"255")
     assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0                              # ... and do not on a 255-CU device (symmetric form)
+
+
+def test_planner_follows_the_devices_cu_count(L):
+    """round 5: every "fills the chip" threshold of the planner (tile kind, tail split, split-K forms) is a share of the CUs the device REPORTS, not of a literal 256:
+    on a whole MI355X (256) the plans are round 4's; a partitioned or CU-masked device (PQ_FAKE_CUS = 128 / 64 / 32) gets plans made for it."""
+    name = lambda M, N, K: L.pq_gemm_variant_name(M, N, K, K, K).decode()      # noqa: E731
+    L.pq_set_option(b"PQ_FAKE_CUS", b"256")
+    full = {s: name(*s) for s in ((2048, 11008, 4096), (4096, 1024, 8192), (4096, 2048, 4096), (512, 4096, 4096), (4096, 14336, 4096))}
+    assert full == {(2048, 11008, 4096): "sp256_16x16x64 + sp128 tail (N)", (4096, 1024, 8192): "ring128_16x16x64", (4096, 2048, 4096): "sp128x256_16x16x64",
+                    (512, 4096, 4096): "ring64x128_16x16x64", (4096, 14336, 4096): "sp256_16x16x64 + sp128 tail (N)"}
+    L.pq_set_option(b"PQ_FAKE_CUS", b"")
+    assert {s: name(*s) for s in full} == full            # (no GPU here: the query falls back to 256; on the GPU box the real count — 256 — gives the same)
+    L.pq_set_option(b"PQ_FAKE_CUS", b"128")
+    assert name(4096, 1024, 8192) == "sp128x256_16x16x64" and name(4096, 2048, 4096) == "sp256_16x16x64" and name(512, 4096, 4096) == "ring128_16x16x64"
+    assert name(2048, 11008, 4096) == "sp256_16x16x64"    # 344 tiles on 128 CUs: 2.7 rounds, no poorly filled tail worth a second launch
+    assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == 0          # 128 tiles fill this device: no K split
+    L.pq_set_option(b"PQ_FAKE_CUS", b"64")
+    assert name(4096, 1024, 8192) == "sp256_16x16x64" and name(1024, 1024, 4096) == "ring128_16x16x64"
+    assert L.pq_qlinear_workspace_bytes(1024, 2048, 11264) == _fsk_bytes(32, 2)      # the half-filled grid of THIS device gets the fused split-K
+    L.pq_set_option(b"PQ_FAKE_CUS", b"32")
+    assert name(1024, 1024, 4096) == "sp128x256_16x16x64" and name(4096, 1280, 8192) == "sp256_16x16x64 + sp128 tail (N)"
+    L.pq_set_option(b"PQ_FAKE_CUS", b"")
