@@ -553,16 +553,21 @@ def run_llama70b_shard(args):
     # the gathered 4096 x 28672 activation on every rank (and the gather of bf16 gate AND up: 4 bytes per intermediate element instead of 1) is gone.
     int8x = None
     try:
-        from protoquant_amd.qtensor import silu_mul_quantize_with_amax, silu_mul_rowamax
+        from protoquant_amd.qtensor import quantize_with_amax, rowamax, silu_mul_quantize_with_amax, silu_mul_rowamax
         ig = I // G
         stacked = torch.randint(-127, 128, (G, M, ig), device=dev, dtype=torch.int8)          # stands for the all-gathered code blocks
         stacked_scale = torch.rand(M, device=dev) * 1e-2 + 1e-4
+        # ... and the same exchange in front of `o` (ColumnShardedQLinear.forward_sharded_input): the rank's heads of the attention output [M, H / G] are quantised
+        # locally against the all-reduced amax and the int8 blocks gathered — instead of K1 on the gathered bf16 [M, H] on every rank
+        x_att = torch.randn(M, H // G, device=dev).to(torch.bfloat16)
+        stacked_o = torch.randint(-127, 128, (G, M, H // G), device=dev, dtype=torch.int8)
 
         def fwd_int8():
             for l in range(L):
                 qkv, o, gu, down = layers[l % NL]
                 qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-                o(x_h)
+                quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0])
+                pq.qlinear_s8_kslabs(stacked_o, stacked_scale, o.wq, o.ws, None, torch.bfloat16)
                 g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(ig, dim=-1)
                 am = silu_mul_rowamax(g_, u_)
                 silu_mul_quantize_with_amax(g_, u_, am, out=stacked[0])
@@ -578,7 +583,8 @@ def run_llama70b_shard(args):
         hop_bf16 = 2 * (2.0 * M * ig) / XG + 2 * 2 * (2.0 * M * I * 2) / 5e12       # gather of the bf16 gate and up shards (one link per peer, all links at once) + their layout passes
         hop_int8 = (4.0 * M) / XG + (1.0 * M * ig) / XG                             # all-reduce of M amax patterns (latency-bound in practice) + gather of the int8 blocks; no layout pass
         int8x = {"ms_per_step": round(di * 1e3, 3), "value": round(ops / di / 1e12, 2), "unit": "TOPS", "us_per_layer": round((di - 0) / L * 1e6, 1),
-                 "what": "per layer: rmsnorm x2, qkv shard, K1 + o shard, gate+up shard, silu*mul row amax + encode on the LOCAL 3584 channels, down shard on the stacked int8 blocks (slabs walked in place)",
+                 "what": "per layer: rmsnorm x2, qkv shard, row amax + encode of the LOCAL 1024 attention features, o shard on the stacked int8 blocks, gate+up shard, "
+                         "silu*mul row amax + encode on the LOCAL 3584 channels, down shard on the stacked int8 blocks (slabs walked in place)",
                  "modelled_gate_up_to_down_hop_us": {"bf16_gather_of_gate_and_up_plus_layout": round(hop_bf16 * 1e6, 1), "int8_code_exchange": round(hop_int8 * 1e6, 1),
                                                      "model": "bytes over one direct xGMI link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s; NOT measured"}}
     except Exception as e:      # an extra figure must never lose the main line
@@ -613,7 +619,9 @@ def run_llama70b_shard(args):
             gu_out = layers[0][2](qn)
             g0, u0 = gu_out.split(I // G, dim=-1)
             am0 = silu_mul_rowamax(g0, u0)
-            extra_items = [("silu*mul row amax, local 4096 x 3584 (int8-code exchange)", None, lambda l: silu_mul_rowamax(g0, u0), 1),
+            extra_items = [("row amax + encode of the local attention features 4096 x 1024 (two launches)", None, lambda l: quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0]), 1),
+                           ("o shard on stacked int8 blocks [8, 4096, 1024]", (M, n_o, H), lambda l: pq.qlinear_s8_kslabs(stacked_o, stacked_scale, layers[l][1].wq, layers[l][1].ws, None, torch.bfloat16), 1),
+                           ("silu*mul row amax, local 4096 x 3584 (int8-code exchange)", None, lambda l: silu_mul_rowamax(g0, u0), 1),
                            ("silu*mul encode against the global amax, local 4096 x 3584", None, lambda l: silu_mul_quantize_with_amax(g0, u0, am0, out=stacked[0]), 1),
                            ("down shard on stacked int8 blocks [8, 4096, 3584]", (M, n_down, I), lambda l: pq.qlinear_s8_kslabs(stacked, stacked_scale, layers[l][3].wq, layers[l][3].ws, None, torch.bfloat16), 1)]
         per_shape, tot = [], 0.0
@@ -637,7 +645,9 @@ def run_llama70b_shard(args):
         if int8x is not None:
             def layer_int8(l):
                 qkv, o, gu, down = layers[l]
-                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); o(x_h)
+                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
+                quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0])
+                pq.qlinear_s8_kslabs(stacked_o, stacked_scale, o.wq, o.ws, None, torch.bfloat16)
                 g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(I // G, dim=-1)
                 silu_mul_quantize_with_amax(g_, u_, silu_mul_rowamax(g_, u_), out=stacked[0])
                 pq.qlinear_s8_kslabs(stacked, stacked_scale, down.wq, down.ws, None, torch.bfloat16)
@@ -1112,8 +1122,9 @@ def run_tp(args, world, rank, dev, dist):
             except Exception as e:
                 print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
                 results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": True}
+            ok_everywhere = all_min("error" not in results[leg.name])   # (still under the leg's watchdog: a rank that raised is out of step with the others' collectives)
             dog.disarm()
-            if not all_min("error" not in results[leg.name]):      # a leg that raised on one rank left the ranks out of step: stop trying native legs
+            if not ok_everywhere:                                       # stop trying native legs
                 shared["native_state"] = "failed"
                 break
 

@@ -93,6 +93,13 @@ int32_t pq_silu_mul_rowamax(const void* g, int64_t ld_g, const void* u, int64_t 
 int32_t pq_silu_mul_quant_rowwise_amax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
                                        const uint32_t* amax_bits, int8_t* q, int64_t ld_q, float* scale, void* stream);
 
+/* The same two halves for a PLAIN activation whose columns are sharded over ranks (a rank's heads of the attention output feeding a column-sharded `o`
+ * projection): pq_quant_rowamax -> all-reduce(max) -> pq_quant_rowwise_amax give the column block of pq_quant_rowwise's codes on the whole row and its scale
+ * vector, bit for bit (QSPEC Q1-Q6; wide rows past 32 768 / 16 384 columns per rank and unaligned operands take the generic kernels). */
+int32_t pq_quant_rowamax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, uint32_t* amax_bits, void* stream);
+int32_t pq_quant_rowwise_amax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, const uint32_t* amax_bits, int8_t* q, int64_t ld_q,
+                              float* scale, void* stream);
+
 /* K1 fused into RMSNorm: quantize(weight * (x.float() * rsqrt(mean(x.float()^2) + eps)).to(dtype)) per
  * token in one pass — the input of the q/k/v and gate/up projections of a decoder layer.  x: [rows, cols], weight: [cols],
  * both of `dtype`; h_out (nullable, ld_h): also store the normalised activation.  Numerics: QSPEC N1-N6 — the sum of squares

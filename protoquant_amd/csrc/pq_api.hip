@@ -18,7 +18,7 @@ template <int DT> void rmsnorm_quant_dispatch(const void*, int64_t, const void*,
 template <int ODT> void dequant_dispatch(const int8_t*, int64_t, const float*, int, int64_t, int64_t, void*, int64_t, hipStream_t);
 template <int OUT> void launch_gemm_generic(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 template <int OUT, int TM, int TN> void launch_gemm_fast(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
-template <int DT, int MODE> void silu_mul_split_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
+template <int DT, int MODE, bool IDENT> void silu_mul_split_dispatch(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
 template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
 template <int OUT> void launch_gemm_ringt(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
 template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
@@ -398,9 +398,9 @@ int32_t pq_silu_mul_rowamax(const void* g, int64_t ld_g, const void* u, int64_t 
     if (rows == 0) return PQ_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (dtype) {
-        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
-        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
-        default: pq::silu_mul_split_dispatch<PQ_F32, 1>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 1, false>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 1, false>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 1, false>(g, ld_g, u, ld_u, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
     }
     return check_launch("pq_silu_mul_rowamax");
 }
@@ -415,11 +415,43 @@ int32_t pq_silu_mul_quant_rowwise_amax(const void* g, int64_t ld_g, const void* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t* ab = const_cast<uint32_t*>(amax_bits);          // (read-only in this mode)
     switch (dtype) {
-        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
-        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
-        default: pq::silu_mul_split_dispatch<PQ_F32, 2>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 2, false>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 2, false>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 2, false>(g, ld_g, u, ld_u, rows, cols, ab, q, ld_q, scale, st); break;
     }
     return check_launch("pq_silu_mul_quant_rowwise_amax");
+}
+
+int32_t pq_quant_rowamax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, uint32_t* amax_bits, void* stream) {
+    Range range_("pq:quant_rowamax (K1, amax half)");
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_rowamax: unknown dtype %d", dtype);
+    if (bad_mat(x, rows, cols, ld_x) || (rows > 0 && !amax_bits))
+        return fail(PQ_ERR_BAD_ARG, "pq_quant_rowamax: bad matrix (rows=%lld cols=%lld ld_x=%lld)", (long long)rows, (long long)cols, (long long)ld_x);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 1, true>(x, ld_x, nullptr, 0, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 1, true>(x, ld_x, nullptr, 0, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 1, true>(x, ld_x, nullptr, 0, rows, cols, amax_bits, nullptr, 0, nullptr, st); break;
+    }
+    return check_launch("pq_quant_rowamax");
+}
+
+int32_t pq_quant_rowwise_amax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x, const uint32_t* amax_bits, int8_t* q, int64_t ld_q,
+                              float* scale, void* stream) {
+    Range range_("pq:quant_rowwise_amax (K1, encode half)");
+    if (dtype < 0 || dtype > 2) return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise_amax: unknown dtype %d", dtype);
+    if (bad_mat(x, rows, cols, ld_x) || bad_mat(q, rows, cols, ld_q) || (rows > 0 && (!scale || !amax_bits)))
+        return fail(PQ_ERR_BAD_ARG, "pq_quant_rowwise_amax: bad matrix (rows=%lld cols=%lld ld_x=%lld ld_q=%lld)", (long long)rows, (long long)cols, (long long)ld_x, (long long)ld_q);
+    if (rows == 0) return PQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* ab = const_cast<uint32_t*>(amax_bits);          // (read-only in this mode)
+    switch (dtype) {
+        case PQ_BF16: pq::silu_mul_split_dispatch<PQ_BF16, 2, true>(x, ld_x, nullptr, 0, rows, cols, ab, q, ld_q, scale, st); break;
+        case PQ_FP16: pq::silu_mul_split_dispatch<PQ_FP16, 2, true>(x, ld_x, nullptr, 0, rows, cols, ab, q, ld_q, scale, st); break;
+        default: pq::silu_mul_split_dispatch<PQ_F32, 2, true>(x, ld_x, nullptr, 0, rows, cols, ab, q, ld_q, scale, st); break;
+    }
+    return check_launch("pq_quant_rowwise_amax");
 }
 
 int32_t pq_rmsnorm_quant_rowwise(const void* x, int64_t ld_x, const void* weight, float eps, int32_t dtype, int64_t rows, int64_t cols,

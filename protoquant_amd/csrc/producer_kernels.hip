@@ -289,7 +289,9 @@ __device__ __forceinline__ void reduce_and_encode(const v4u (&hv)[VPT], uint32_t
 // 143 VGPRs, 3 waves per SIMD in a kernel that is VALU-bound before it is HBM-bound; 512 threads x 3-4 vectors need < 100.
 // MODE 0: K1s (amax + encode).  MODE 1: the row amax only (amax_io[row] = f32 bit pattern of max |h| over these columns; nothing else is written).
 // MODE 2: encode against the row amax GIVEN in amax_io (the max over every rank's columns): no reduction; writes codes and the scale.
-template <int DT, int VPT, int TPR, bool WRITE_H, int MODE = 0>
+// IDENT (MODE 1 / 2 only): h = g itself — the same two halves for a PLAIN column-sharded activation (a rank's heads of the attention output feeding a
+// column-sharded `o` projection: pq_quant_rowamax / pq_quant_rowwise_amax); u is not read.
+template <int DT, int VPT, int TPR, bool WRITE_H, int MODE = 0, bool IDENT = false>
 __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(const uint8_t* __restrict__ g, int64_t ldg_bytes,
                                                           const uint8_t* __restrict__ u, int64_t ldu_bytes, int64_t rows,
                                                           int nvec, int8_t* __restrict__ q, int64_t ldq,
@@ -311,20 +313,23 @@ __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(cons
         const int idx = i * TPR + t;
         const int64_t off = (int64_t)(idx < nvec ? idx : nvec - 1) * 16;
         gv[i] = *reinterpret_cast<const v4u*>(gr + off);
-        uv[i] = *reinterpret_cast<const v4u*>(ur + off);
+        if constexpr (!IDENT) uv[i] = *reinterpret_cast<const v4u*>(ur + off);
     }
     v4u hv[VPT];
     uint32_t ab = 0;
     uint32_t gmn = 0xFFFFFFFFu, gmx = 0u;
+    if constexpr (!IDENT) {
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) vec_absminmax_bits<DT>(gv[i], gmn, gmx);
-    const bool fast_div = __builtin_amdgcn_ballot_w64(!silu_fast_div_ok<DT>(gmn, gmx)) == 0ull;   // wave-uniform
+        for (int i = 0; i < VPT; ++i) vec_absminmax_bits<DT>(gv[i], gmn, gmx);
+    }
+    const bool fast_div = IDENT || __builtin_amdgcn_ballot_w64(!silu_fast_div_ok<DT>(gmn, gmx)) == 0ull;   // wave-uniform
     auto produce = [&](auto fast) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = i * TPR + t;
             // slots past the row's end (whole waves of them when the width is not VPT * TPR vectors) skip the arithmetic
-            hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
+            if constexpr (IDENT) hv[i] = idx < nvec ? gv[i] : v4u{0u, 0u, 0u, 0u};
+            else hv[i] = idx < nvec ? silu_mul_vec<DT, decltype(fast)::value>(gv[i], uv[i]) : v4u{0u, 0u, 0u, 0u};
             if constexpr (MODE != 2) ab = vec_amax_bits<DT>(hv[i], ab);
             if constexpr (WRITE_H) {
                 if (active && idx < nvec) store_wt_b128(h_out + row * ldh_bytes + (int64_t)idx * 16, hv[i]);
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(TPR > 256 ? TPR : 256) void silu_mul_quant_vec(cons
 }
 
 // generic path: any cols / leading dimensions / alignment.  One block per row; h is recomputed in the second pass.
-template <int DT, int MODE = 0>
+template <int DT, int MODE = 0, bool IDENT = false>
 __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __restrict__ g, int64_t ldg, const void* __restrict__ u,
                                                               int64_t ldu, int64_t cols, int8_t* __restrict__ q, int64_t ldq,
                                                               float* __restrict__ scale, void* __restrict__ h_out, int64_t ldh,
@@ -353,7 +358,10 @@ __global__ __launch_bounds__(256) void silu_mul_quant_generic(const void* __rest
     const int64_t row = blockIdx.x;
     const S* gr = reinterpret_cast<const S*>(g) + row * ldg;
     const S* ur = reinterpret_cast<const S*>(u) + row * ldu;
-    auto h_at = [&](int64_t c) -> S { return Elem<DT>::from_f32(silu_mul_spec<DT>(Elem<DT>::to_f32(gr[c]), Elem<DT>::to_f32(ur[c]))); };
+    auto h_at = [&](int64_t c) -> S {
+        if constexpr (IDENT) return gr[c];
+        else return Elem<DT>::from_f32(silu_mul_spec<DT>(Elem<DT>::to_f32(gr[c]), Elem<DT>::to_f32(ur[c])));
+    };
     float amax = 0.0f;
     if constexpr (MODE == 2) {
         amax = __builtin_bit_cast(float, amax_io[row]);
@@ -580,23 +588,23 @@ static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cas
 // vectors the 256-thread block per row (2 vectors per thread, ~44 VGPRs) is 10 % faster at 4096 rows (15.7 -> 14.2 us) and equal at 16384;
 // at 256 vectors the wave layout wins (8.7 vs 9.6 us).  Same bits either way (QSPEC N1-N3 pins the order of the sum).
 
-template <int DT, int TPR, bool WRITE_H, int MODE = 0>
+template <int DT, int TPR, bool WRITE_H, int MODE = 0, bool IDENT = false>
 static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const uint8_t* u, int64_t ldu_b, int64_t rows, int nvec,
                                 int8_t* q, int64_t ldq, float* scale, uint8_t* h, int64_t ldh_b, hipStream_t st, uint32_t* amax_io = nullptr) {
     constexpr int BS = TPR > 256 ? TPR : 256, RPB = BS / TPR;
     const dim3 grid((unsigned)((rows + RPB - 1) / RPB)), block(BS);
     switch (vpt) {
-        case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
-        case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
+        case 1: silu_mul_quant_vec<DT, 1, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
+        case 2: silu_mul_quant_vec<DT, 2, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
         case 3:
-            if constexpr (TPR == 512) silu_mul_quant_vec<DT, 3, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
+            if constexpr (TPR == 512) silu_mul_quant_vec<DT, 3, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
-        case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
+        case 4: silu_mul_quant_vec<DT, 4, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io); break;
         case 8:
-            if constexpr (TPR != 512) silu_mul_quant_vec<DT, 8, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
+            if constexpr (TPR != 512) silu_mul_quant_vec<DT, 8, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
         default:
-            if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H, MODE><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
+            if constexpr (TPR == 256) silu_mul_quant_vec<DT, 16, TPR, WRITE_H, MODE, IDENT><<<grid, block, 0, st>>>(g, ldg_b, u, ldu_b, rows, nvec, q, ldq, scale, h, ldh_b, amax_io);
             break;
     }
 }
@@ -604,15 +612,16 @@ static void launch_silu_mul_vec(int vpt, const uint8_t* g, int64_t ldg_b, const 
 // the two halves of K1s for a column-sharded intermediate (MODE 1: row amax of these columns -> amax_io; MODE 2: encode against the amax in amax_io).
 // Same layouts as the fused kernel (the h vectors are recomputed in MODE 2 — g and u are read twice, from the Infinity Cache the second time — instead of
 // parking a 16-bit h in HBM between the two passes: the same 9 bytes per element either way, and no extra buffer).
-template <int DT, int MODE>
+template <int DT, int MODE, bool IDENT>
 void silu_mul_split_dispatch(const void* g, int64_t ldg, const void* u, int64_t ldu, int64_t rows, int64_t cols, uint32_t* amax_io, int8_t* q,
                              int64_t ldq, float* scale, hipStream_t st) {
     static_assert(MODE == 1 || MODE == 2, "split modes");
     constexpr int EPV = 16 / Elem<DT>::kBytes;
+    if constexpr (IDENT) { u = g; ldu = ldg; }          // (never read)
     const bool vec_ok = cols > 0 && (cols % EPV == 0) && (ldg % EPV == 0) && (ldu % EPV == 0) && aligned_to(g, 16) && aligned_to(u, 16) &&
                         cols / EPV <= 256 * 16 && (MODE == 1 || ((ldq % EPV == 0) && aligned_to(q, EPV)));
     if (!vec_ok) {
-        silu_mul_quant_generic<DT, MODE><<<dim3((unsigned)rows), dim3(256), 0, st>>>(g, ldg, u, ldu, cols, q, ldq, scale, nullptr, 0, amax_io);
+        silu_mul_quant_generic<DT, MODE, IDENT><<<dim3((unsigned)rows), dim3(256), 0, st>>>(g, ldg, u, ldu, cols, q, ldq, scale, nullptr, 0, amax_io);
         return;
     }
     const int nvec = (int)(cols / EPV);
@@ -620,9 +629,9 @@ void silu_mul_split_dispatch(const void* g, int64_t ldg, const void* u, int64_t 
     const uint8_t* gb = reinterpret_cast<const uint8_t*>(g);
     const uint8_t* ub = reinterpret_cast<const uint8_t*>(u);
     const int64_t kb = Elem<DT>::kBytes;
-    if (nvec <= 64 * 4) launch_silu_mul_vec<DT, 64, false, MODE>(pow2((nvec + 63) / 64), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
-    else if (nvec > 1024 && nvec <= 1536 && opt().silu_tpr != 256) launch_silu_mul_vec<DT, 512, false, MODE>((nvec + 511) / 512, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
-    else launch_silu_mul_vec<DT, 256, false, MODE>(pow2((nvec + 255) / 256), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
+    if (nvec <= 64 * 4) launch_silu_mul_vec<DT, 64, false, MODE, IDENT>(pow2((nvec + 63) / 64), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
+    else if (!IDENT && nvec > 1024 && nvec <= 1536 && opt().silu_tpr != 256) launch_silu_mul_vec<DT, 512, false, MODE, IDENT>((nvec + 511) / 512, gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
+    else launch_silu_mul_vec<DT, 256, false, MODE, IDENT>(pow2((nvec + 255) / 256), gb, ldg * kb, ub, ldu * kb, rows, nvec, q, ldq, scale, nullptr, 0, st, amax_io);
 }
 
 template <int DT>
@@ -712,8 +721,10 @@ template void rmsnorm_quant_dispatch<PQ_FP16>(const void*, int64_t, const void*,
 template void rmsnorm_quant_dispatch<PQ_F32>(const void*, int64_t, const void*, float, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);
 
 #define PQ_SPLIT_INST(DT) \
-    template void silu_mul_split_dispatch<DT, 1>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t); \
-    template void silu_mul_split_dispatch<DT, 2>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
+    template void silu_mul_split_dispatch<DT, 1, false>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t); \
+    template void silu_mul_split_dispatch<DT, 2, false>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t); \
+    template void silu_mul_split_dispatch<DT, 1, true>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t); \
+    template void silu_mul_split_dispatch<DT, 2, true>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, uint32_t*, int8_t*, int64_t, float*, hipStream_t);
 PQ_SPLIT_INST(PQ_BF16) PQ_SPLIT_INST(PQ_FP16) PQ_SPLIT_INST(PQ_F32)
 #undef PQ_SPLIT_INST
 template void silu_mul_quant_dispatch<PQ_BF16>(const void*, int64_t, const void*, int64_t, int64_t, int64_t, int8_t*, int64_t, float*, void*, int64_t, hipStream_t);

@@ -143,6 +143,41 @@ def silu_mul_quantize_with_amax(g: torch.Tensor, u: torch.Tensor, amax_bits: tor
     return QTensor(q if out is not None else q.reshape(g.shape), scale, 1, g.dtype, g.shape)
 
 
+def rowamax(x: torch.Tensor) -> torch.Tensor:
+    """First half of quantize(x, axis=-1) for an activation whose COLUMNS are sharded over ranks: per token, the f32 bit pattern (int32 [rows]) of max |x| over
+    the columns this rank holds; an integer MAX over the ranks is the exact, NaN-propagating row amax."""
+    L.require_gpu(x, "rowamax(x)")
+    code = L.dtype_code(x.dtype)
+    x2 = _rows_view(x)
+    rows, cols = x2.shape
+    amax = torch.empty((rows,), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().pq_quant_rowamax(x2.data_ptr(), code, rows, cols, L.ld(x2), amax.data_ptr(), L.stream_ptr(x)), "rowamax")
+    return amax
+
+
+def quantize_with_amax(x: torch.Tensor, amax_bits: torch.Tensor, out: torch.Tensor | None = None) -> QTensor:
+    """Second half: the int8 codes of THESE columns against the row amax given as f32 bit patterns (int32 [rows]: the max over every rank's columns) and the
+    row scales — the column block and the scale vector of quantize(x_whole, axis=-1), bit for bit."""
+    L.require_gpu(x, "quantize_with_amax(x)")
+    code = L.dtype_code(x.dtype)
+    x2 = _rows_view(x)
+    rows, cols = x2.shape
+    if amax_bits.dtype != torch.int32 or amax_bits.shape != (rows,) or amax_bits.device != x.device or not amax_bits.is_contiguous():
+        raise ValueError(f"quantize_with_amax: amax_bits must be a contiguous int32 [{rows}] tensor on {x.device}")
+    if out is None:
+        q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+    else:
+        q = out
+        if q.dtype != torch.int8 or q.shape != (rows, cols) or q.device != x.device or (cols > 1 and q.stride(1) != 1):
+            raise ValueError(f"quantize_with_amax: out must be an int8 [{rows}, {cols}] tensor with contiguous rows")
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().pq_quant_rowwise_amax(x2.data_ptr(), code, rows, cols, L.ld(x2), amax_bits.data_ptr(), q.data_ptr(), L.ld(q) if rows > 1 else max(cols, 1),
+                                              scale.data_ptr(), L.stream_ptr(x)), "quantize_with_amax")
+    return QTensor(q if out is not None else q.reshape(x.shape), scale, 1, x.dtype, x.shape)
+
+
 def rmsnorm_quantize(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, return_h: bool = False):
     """quantize(weight * (x.float() * rsqrt(mean(x.float()**2, -1) + eps)).to(x.dtype), axis=-1) in ONE pass (kernel K1
     fused into RMSNorm): the normalised activation feeding q/k/v or gate/up is reduced, scaled and encoded in registers.

@@ -17,7 +17,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .qlinear import FusedQLinear, gemm_operands, qlinear, qlinear_s8, qlinear_s8_kslabs, qlinear_s8_t
-from .qtensor import QTensor, quantize, silu_mul_quantize, silu_mul_quantize_with_amax, silu_mul_rowamax
+from .qtensor import QTensor, quantize, quantize_with_amax, rowamax, silu_mul_quantize, silu_mul_quantize_with_amax, silu_mul_rowamax
 
 
 def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
@@ -234,6 +234,28 @@ def gather_rows_t(yt_local: torch.Tensor, n_total: int, group=None) -> torch.Ten
     return out
 
 
+def allreduce_max_bits(bits: torch.Tensor, world: int, native: "RcclColumnGather | None" = None, group=None) -> torch.Tensor:
+    """In-place exact MAX over the ranks of int32 f32-bit-patterns of non-negative values (sign bit clear: the signed and the unsigned order agree; NaNs sort above +Inf)."""
+    if world == 1:
+        return bits
+    if native is not None:
+        return native.allreduce_max_(bits)
+    dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+    return bits
+
+
+def gather_stacked(block: torch.Tensor, world: int, native: "RcclColumnGather | None" = None, group=None) -> torch.Tensor:
+    """Contiguous all-gather of equal blocks -> [world, *block.shape] (the layout an all-gather leaves; consumers walk it in place: qlinear_s8_kslabs)."""
+    if native is not None:
+        return native.gather_stacked(block.contiguous())
+    out = block.new_empty((world, *block.shape))
+    if world == 1:
+        out[0].copy_(block)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), block.contiguous().view(-1), group=group)
+    return out
+
+
 class ColumnShardedQLinear(nn.Module):
     """qlinear whose int8 weight rows [n0:n1) live on this rank; forward returns the full y[..., N].
 
@@ -293,6 +315,36 @@ class ColumnShardedQLinear(nn.Module):
         yt_local = self._local_t(codes, xq.scale, x.dtype)
         return self.native_gather.gather_t(yt_local, self.out_features) if self.native_gather is not None else \
             gather_rows_t(yt_local, self.out_features, self.group)
+
+    # device steps of forward_sharded_input (stubbed in tests/test_dist_gloo.py)
+    def _local_amax(self, x2):
+        return rowamax(x2)
+
+    def _encode(self, x2, amax_bits):
+        return quantize_with_amax(x2, amax_bits)
+
+    def _local_rows_stacked(self, stacked, scales, dtype):
+        return qlinear_s8_kslabs(stacked, scales, self.local.wq, self.local.ws, self.local.bias, dtype)
+
+    def forward_sharded_input(self, x_local: torch.Tensor) -> torch.Tensor:
+        """The input activation is itself COLUMN-sharded: x_local[..., K/G] is this rank's block of the K input features (its heads of the attention output in front of a
+        column-sharded `o` projection).  Instead of gathering the bf16 blocks and quantising the whole [M, K] activation on every rank, the int8 CODES travel (as in
+        ColumnShardedGatedMLP): local row amax -> ONE all-reduce(max) of M 32-bit patterns -> local encode against the global amax -> all-gather of the int8 blocks
+        (1 byte per element instead of 2, each column quantised once) -> this rank's weight rows against the stacked blocks, walked in place.  The result is forward()'s
+        on the concatenated activation, bit for bit (max is exact and order-free).  Needs in_features % world == 0; layout "rows" only."""
+        world, rank = (self.native_gather.world, self.native_gather.rank) if self.native_gather is not None else (dist.get_world_size(self.group), dist.get_rank(self.group))
+        if self.in_features % world or x_local.shape[-1] != self.in_features // world:
+            raise ValueError(f"forward_sharded_input: expected [..., {self.in_features}/{world}] input features, got {x_local.shape[-1]}")
+        x2 = x_local.reshape(-1, x_local.shape[-1])
+        amax = allreduce_max_bits(self._local_amax(x2), world, self.native_gather, self.group)
+        xq = self._encode(x2, amax)
+        stacked = gather_stacked(xq.int_data.reshape(x2.shape), world, self.native_gather, self.group)
+        y_local = self._local_rows_stacked(stacked, xq.scale, x_local.dtype)
+        if self.native_gather is not None:
+            y = self.native_gather(y_local, self.out_features)
+        else:
+            y = y_local if world == 1 else gather_columns(y_local, self.out_features, self.group)
+        return y.reshape(*x_local.shape[:-1], self.out_features)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.layout == "transposed":
@@ -384,22 +436,10 @@ class ColumnShardedGatedMLP(nn.Module):
 
     # ---- exchange steps
     def _amax_allreduce(self, bits):
-        if self.world == 1:
-            return bits
-        if self.native is not None:
-            return self.native.allreduce_max_(bits)
-        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)      # int32 max == unsigned max here: every pattern has its sign bit clear
-        return bits
+        return allreduce_max_bits(bits, self.world, self.native, self.group)
 
     def _gather_codes(self, codes):
-        if self.native is not None:
-            return self.native.gather_stacked(codes)
-        out = codes.new_empty((self.world, *codes.shape))
-        if self.world == 1:
-            out[0].copy_(codes)
-        else:
-            dist.all_gather_into_tensor(out.view(-1), codes.contiguous().view(-1), group=self.group)
-        return out
+        return gather_stacked(codes, self.world, self.native, self.group)
 
     def _gather_out(self, y_local):
         if self.native is not None:

@@ -91,6 +91,19 @@ def main():
                 out.zero_(); g.replay()
             torch.cuda.synchronize()
         assert torch.equal(bits(out)[~nan0], bits(y0)[~nan0]), (rank, "int8-code exchange, graph replay", M, H, I)
+    # ... and in front of a plain column-sharded projection: every rank holds K / world input features (its heads of an attention output) and N / world output channels
+    for (M, N, K) in ((300, 384, 1024), (4096, 1024, 2048)):
+        if K % world:
+            continue
+        torch.manual_seed(3 + K)
+        lin = torch.nn.Linear(K, N, bias=True, device="cuda", dtype=torch.bfloat16)
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        y0 = pq.qlinear.from_linear(lin)(x)
+        k0, k1 = shard_bounds(K, world, rank)
+        m = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather)
+        y1 = m.forward_sharded_input(x[:, k0:k1])
+        torch.cuda.synchronize()
+        assert torch.equal(bits(y1), bits(y0)), (rank, "sharded input", M, N, K)
     dist.barrier()
     gather.close()
     dist.destroy_process_group()

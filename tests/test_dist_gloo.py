@@ -305,3 +305,74 @@ def test_column_sharded_gated_mlp_forward_world2(M, H, I):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _csi_worker(rank, world, port, M, N, K, q):
+    """ColumnShardedQLinear.forward_sharded_input over gloo with the device steps replaced by the numpy oracle: the exchange (integer all-reduce(max), all-gather of the
+    int8 blocks into the stacked layout, gather of the output shards) must reproduce the oracle's unsharded qlinear on the concatenated activation, bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+
+        import numpy as np
+        from oracle import qspec_numpy as Q
+        from protoquant_amd.qtensor import QTensor
+        from protoquant_amd.sharded import ColumnShardedQLinear, shard_bounds
+
+        rng = np.random.default_rng(21)
+        x = Q.from_f32(rng.standard_normal((M, K)).astype(np.float32), 0)
+        x[2, K - 1] = 0x7F80                                     # +Inf in the LAST rank's block: its row amax must reach every rank
+        w = Q.from_f32((rng.standard_normal((N, K)) * 0.05).astype(np.float32), 0)
+        wq, ws = Q.quantize(w, 0, 1)
+        y_want, xq_want, xs_want, _ = Q.qlinear(x, 0, wq, ws, None)
+        lo, hi = shard_bounds(N, world, rank)
+        k0, k1 = shard_bounds(K, world, rank)
+        bf = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.bfloat16)     # noqa: E731
+        nb = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)                          # noqa: E731
+
+        class Stub(ColumnShardedQLinear):
+            def _local_amax(self, x2):
+                return torch.from_numpy(Q.row_amax_bits(nb(x2), 0).view(np.int32).copy())
+
+            def _encode(self, x2, amax_bits):
+                qq, ss = Q.quantize_rows_with_amax(nb(x2), 0, amax_bits.numpy().view(np.uint32))
+                return QTensor(torch.from_numpy(qq), torch.from_numpy(ss), 1, torch.bfloat16, torch.Size(qq.shape))
+
+            def _local_rows_stacked(self, stacked, scales, dtype):
+                G, Mm, kps = stacked.shape
+                codes = stacked.permute(1, 0, 2).reshape(Mm, G * kps).numpy()
+                return bf(Q.epilogue(Q.gemm_s8s8s32(codes, wq[lo:hi]), scales.numpy(), ws[lo:hi], None, 0))
+
+        m = Stub.__new__(Stub)
+        torch.nn.Module.__init__(m)
+        m.local = types.SimpleNamespace(in_features=K, out_features=hi - lo)
+        m.out_features, m.group, m.in_features, m.native_gather, m.overlap_chunks, m.layout, m.transposed_view = N, None, K, None, 1, "rows", False
+        y = m.forward_sharded_input(bf(x[:, k0:k1]))
+        nan = np.isnan(Q.to_f32(y_want, 0))
+        got = nb(y)
+        ok = tuple(y.shape) == (M, N) and np.array_equal(np.isnan(y.float().numpy()), nan) and np.array_equal(got[~nan], y_want[~nan]) and bool(nan[2].all())
+        y3 = m.forward_sharded_input(bf(x[:, k0:k1]).reshape(2, M // 2, k1 - k0))
+        ok = ok and tuple(y3.shape) == (2, M // 2, N)
+        q.put((rank, bool(ok)))
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,N,K", [(12, 64, 96), (6, 63, 128)])
+def test_column_sharded_qlinear_sharded_input_world2(M, N, K):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_csi_worker, args=(r, world, port, M, N, K, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

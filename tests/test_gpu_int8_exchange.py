@@ -65,6 +65,53 @@ def test_split_silu_quant_equals_the_fused_kernel_and_the_oracle(pq, code, rows,
     assert torch.equal(one.int_data, q) and torch.equal(one.scale.view(torch.int32), scales[0].view(torch.int32))
 
 
+@pytest.mark.parametrize("code", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,parts", [(64, 8192, 8), (37, 1024, 1), (5, 1000, 3), (130, 4096, 4), (3, 77, 2), (16, 40000, 2)])
+def test_split_plain_quant_equals_k1_and_the_oracle(pq, code, rows, cols, parts):
+    """the same two halves for a PLAIN activation (pq_quant_rowamax / pq_quant_rowwise_amax: a rank's heads of the attention output): block amax, integer max over the
+    blocks, encode per block == the oracle's Q1-Q6 on the whole row == K1; NaN / Inf / zero rows included."""
+    rng = np.random.default_rng(rows * 13 + cols + code)
+    x = (rng.standard_normal((rows, cols)) * 2).astype(np.float32)
+    if rows >= 5:
+        x[1, cols // 2] = np.nan; x[2, 3] = np.inf; x[3, :] = 0; x[4, -1] = -np.inf
+    xs = Q.from_f32(x, code)
+    want_q, want_s = C.quant_rowwise(xs, code)
+    xt = to_gpu(xs, code)
+    blocks = _split(cols, parts)
+    am = [pq.rowamax(xt[:, a:b]) for a, b in blocks]
+    glob = torch.stack(am).max(dim=0).values
+    q = torch.empty((rows, cols), dtype=torch.int8, device="cuda")
+    scales = [pq.quantize_with_amax(xt[:, a:b], glob, out=q[:, a:b]).scale for a, b in blocks]
+    same(q, want_q, "codes of the blocks")
+    for s in scales:
+        same(s, want_s, "row scales")
+    one = pq.quantize(xt)
+    assert torch.equal(one.int_data, q) and torch.equal(one.scale.view(torch.int32), scales[0].view(torch.int32))
+
+
+@pytest.mark.parametrize("M,N,K,G,bias", [(300, 384, 1024, 2, True), (129, 1000, 2048, 8, False), (4096, 8192, 8192, 8, False), (50, 96, 768, 3, True)])
+def test_column_sharded_qlinear_on_a_column_sharded_input(pq, M, N, K, G, bias):
+    """ColumnShardedQLinear.forward_sharded_input with G ranks played offline (the 70B `o` projection at its real shape among them: every rank holds 1024 of the 8192
+    attention-output features and 1024 of the 8192 output channels): the int8-code exchange gives forward()'s result on the concatenated activation, bit for bit."""
+    torch.manual_seed(M + N)
+    lin = torch.nn.Linear(K, N, bias=bias, device="cuda", dtype=torch.bfloat16)
+    x = (torch.randn(M, K, device="cuda") * 1.3).to(torch.bfloat16)
+    y_ref = pq.qlinear.from_linear(lin)(x)
+    qx = pq.quantize(x)
+    mods = [pq.ColumnShardedQLinear.from_linear(lin, world=G, rank=r) for r in range(G)]
+    kb = _split(K, G)
+    am = [m._local_amax(x[:, a:b]) for m, (a, b) in zip(mods, kb)]
+    glob = torch.stack(am).max(dim=0).values
+    enc = [m._encode(x[:, a:b], glob) for m, (a, b) in zip(mods, kb)]
+    stacked = torch.stack([e.int_data for e in enc]).contiguous()
+    assert torch.equal(stacked.permute(1, 0, 2).reshape(M, K), qx.int_data) and all(torch.equal(e.scale.view(torch.int32), qx.scale.view(torch.int32)) for e in enc)
+    ranks = range(G) if M * N * K < 1 << 32 else (0, G - 1)
+    nb = _split(N, G)
+    for r in ranks:
+        y_r = mods[r]._local_rows_stacked(stacked, enc[r].scale, torch.bfloat16)
+        assert torch.equal(y_r.view(torch.int16), y_ref[:, nb[r][0]:nb[r][1]].contiguous().view(torch.int16)), r
+
+
 @pytest.mark.parametrize("M,N,K,G,in_place", [(4096, 1024, 28672, 8, True), (1024, 1024, 8192, 8, True), (2048, 512, 4096, 4, True), (700, 1000, 1024, 2, True),
                                              (256, 4096, 2048, 2, True), (4096, 4096, 4096, 4, False), (2048, 4096, 11008, 2, False), (16, 1024, 8192, 8, False), (37, 50, 384, 3, False),
                                              (300, 640, 960, 5, False)])
@@ -218,6 +265,14 @@ def test_column_sharded_gated_mlp_world1_rccl_under_capture(pq):
                 out.zero_(); gr.replay()
             torch.cuda.synchronize()
         assert torch.equal(out.view(torch.int16), y_ref.view(torch.int16))
+        # the same exchange in front of a plain column-sharded projection (world 1: the "block" is the whole activation)
+        lin = torch.nn.Linear(512, 384, bias=True, device="cuda", dtype=torch.bfloat16)
+        mq = pq.ColumnShardedQLinear.from_linear(lin, native_gather=gather)
+        yq = pq.qlinear.from_linear(lin)(x)
+        assert torch.equal(mq.forward_sharded_input(x).view(torch.int16), yq.view(torch.int16))
+        assert torch.equal(pq.ColumnShardedQLinear.from_linear(lin).forward_sharded_input(x).view(torch.int16), yq.view(torch.int16))
+        with pytest.raises(ValueError):
+            mq.forward_sharded_input(x[..., :100])
         gather.close()
     finally:
         if created:
