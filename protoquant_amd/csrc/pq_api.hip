@@ -542,9 +542,12 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     // this device reports (a CU-masked or partitioned device reports fewer) — otherwise the two-pass split-K or the single-pass tile runs
     const int cus = device_cus();
     if (t256 > cus / 4 && t256 <= cus / 2 && K >= 10240 && K % 256 == 0) return 2;          // (2 * t256 <= cus: the whole grid resident)
-    // (the quarter-filled grid with a very long K — the Llama-70B `down` shard — ran four slices here in round 3: 91 us with the symmetric exchange, 104 in the
-    // placement-independent ticket form; the 128 x 128 ring tile with the rotated K walk does 102 us in one pass with no workspace, so it is no longer planned.
-    // PQ_FSK=4 still forces it.)
+    // the quarter-filled grid with a very long K — the Llama-70B `down` shard, 4096 x 1024 x 28672 — in four slices (4 * t256 <= cus).  Round 3 ran it with the symmetric
+    // exchange (91 us), round 4 dropped the plan when the symmetric form became opt-in (ticket 104 us against 102 for the rotated 128 x 128 ring tile in one pass).
+    // Round 5, three runs on two boxes, weights from HBM (profiles/r05_ab_down_shard_forms.txt): ticket 99.1 - 99.5 us, ring tile 106.0 - 114.6, symmetric 93.4 — the
+    // placement-independent ticket form is 6 - 13 % ahead, so it is planned again (with the caller's workspace; without one the ring tile runs).  Smaller grids
+    // (2048 x 1024 x 28672: 85 us either way) stay with the ring tiles.
+    if (t256 > cus / 8 && t256 <= cus / 4 && K >= 16384 && K % 512 == 0) return 4;
     return 0;
 }
 

@@ -62,11 +62,12 @@ def _fsk_bytes(tiles, S):
 
 def test_planner_refuses_fused_splitk_beyond_the_devices_cus(L):
     """cfg-3 `down` (128 tiles x 2 slices = 256 workgroups): planned on a 256-CU device; on a device that reports fewer CUs (CU-masked / partitioned:
-    PQ_FAKE_CUS) the in-kernel hand-over is refused and the single-pass 128 x 256 tile runs.  (The 70B `down` shard, planned with four slices in round 3,
-    runs the 128 x 128 ring tile with the rotated K walk since round 4: one pass, no workspace.)"""
+    PQ_FAKE_CUS) the in-kernel hand-over is refused and the single-pass 128 x 256 tile runs."""
     L.pq_set_option(b"PQ_FAKE_CUS", b"256")
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == _fsk_bytes(128, 2)
-    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == 0 and L.pq_gemm_variant_name(4096, 1024, 28672, 28672, 28672) == b"ring128_16x16x64"
+    # the 70B `down` shard: four slices in the ticket form again since round 5 (64 tiles x 4 = 256 workgroups; without a workspace the 128 x 128 ring tile runs)
+    assert L.pq_qlinear_workspace_bytes(4096, 1024, 28672) == _fsk_bytes(64, 4) and L.pq_gemm_variant_name(4096, 1024, 28672, 28672, 28672) == b"ring128_16x16x64"
+    assert L.pq_qlinear_workspace_bytes(2048, 1024, 28672) == 0 and L.pq_qlinear_workspace_bytes(4096, 1024, 8192) == 0
     L.pq_set_option(b"PQ_FAKE_CUS", b"255")
     assert L.pq_qlinear_workspace_bytes(2048, 4096, 11008) == 0                              # -> 128 x 256 tiles, one pass
     L.pq_set_option(b"PQ_FAKE_CUS", b"304")
