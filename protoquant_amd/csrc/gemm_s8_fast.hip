@@ -1164,6 +1164,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 2 : 1) void gemm_s8_ring128(co
     // without the layout pass.  kt / tiles by a host-computed reciprocal (exact for kt < 2^16), all scalar.
     auto x_off = [&](int ktu) -> int64_t {
         if (xs.tiles <= 0) return (int64_t)ktu * FBK;
+        if (xs.tiles == 1) return (int64_t)ktu * xs.stride;          // one K-tile per slab (its reciprocal, 2^32, does not fit the 32-bit magic)
         const int sl = (int)(((uint64_t)(uint32_t)ktu * (uint64_t)xs.magic) >> 32);
         return (int64_t)sl * xs.stride + (int64_t)(ktu - sl * xs.tiles) * FBK;
     };

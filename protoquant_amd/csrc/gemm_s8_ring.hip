@@ -84,7 +84,9 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
         const int8_t* gP = gP0 + ktu * FBK;
         // X stacked in K-slabs (pq_qlinear_s8_kslabs, as in gemm_s8_ring128): K-tile kt lives in slab kt / xs.tiles; the division by a host-computed reciprocal, all scalar
         int64_t xo = (int64_t)ktu * FBK;
-        if (xs.tiles > 0) {
+        if (xs.tiles == 1) {
+            xo = (int64_t)ktu * xs.stride;                               // one K-tile per slab (its reciprocal, 2^32, does not fit the 32-bit magic)
+        } else if (xs.tiles > 1) {
             const int sl = (int)(((uint64_t)(uint32_t)ktu * (uint64_t)xs.magic) >> 32);
             xo = (int64_t)sl * xs.stride + (int64_t)(ktu - sl * xs.tiles) * FBK;
         }

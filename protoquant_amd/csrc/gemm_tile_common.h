@@ -66,7 +66,7 @@ inline int rot_chunk_ktiles(int sharers, int tn) {
 // the activation operand as an all-gather leaves int8 codes: K-slab s = [M][k_per_slab] at `stride` bytes per slab (pq_qlinear_s8_kslabs); tiles = 0: plain row-major
 struct KSlabs {
     int tiles = 0;            // K-tiles (128 B) per slab
-    uint32_t magic = 0;       // ceil(2^32 / tiles): kt / tiles == (kt * magic) >> 32 for kt < 2^16
+    uint32_t magic = 0;       // ceil(2^32 / tiles): kt / tiles == (kt * magic) >> 32 for kt < 2^16 (tiles >= 2; tiles == 1 is handled apart: 2^32 does not fit)
     int64_t stride = 0;       // bytes between slabs
 };
 

@@ -1,6 +1,7 @@
 """Fuzz harness (test infrastructure; run by tests/test_gpu_fuzz.py, or directly: `FUZZ_SECONDS=150 python -m tests.fuzz_quant`):
 random shapes / strides / alignments / special values through quantize (both axes), dequantize, silu_mul_quantize,
-rmsnorm_quantize and the fused GEMM epilogue, each compared bit for bit with the oracle."""
+rmsnorm_quantize, the split quantisation halves of the int8-code exchange (random column blocks), the fused GEMM epilogue and the GEMM on stacked
+code blocks, each compared bit for bit with the oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -64,6 +65,18 @@ def run(budget, seed):
       sq, ss, sh = C.silu_mul_quant_rowwise(g, u, code)
       qt, h = pq.silu_mul_quantize(strided(g, code, pad, off), strided(u, code, int(rng.choice([0, 16])), 0), return_h=True)
       bad += eqb(qt.int_data, sq, "K1s q", ctx) + eqb(qt.scale, ss, "K1s s", ctx) + eqb(h, sh, "K1s h", ctx, np.isnan(Q.to_f32(sh, code)))
+      # round 5: the two halves of K1 / K1s over a random column split (strided, ragged, unaligned blocks): integer max of the block amaxes, encode per block
+      parts = int(rng.integers(1, 5))
+      cuts = sorted(set([0, cols] + [int(c) for c in rng.integers(0, cols + 1, parts - 1)]))
+      blocks = [(a_, b_) for a_, b_ in zip(cuts, cuts[1:]) if b_ > a_]
+      gt_, ut_ = strided(g, code, pad, off), strided(u, code, 0, 0)
+      am_x = torch.stack([pq.rowamax(xt[:, a_:b_]) for a_, b_ in blocks]).max(dim=0).values
+      am_h = torch.stack([pq.silu_mul_rowamax(gt_[:, a_:b_], ut_[:, a_:b_]) for a_, b_ in blocks]).max(dim=0).values
+      qx2 = torch.empty((rows, cols), dtype=torch.int8, device="cuda"); qh2 = torch.empty_like(qx2)
+      for a_, b_ in blocks:
+          sx2 = pq.quantize_with_amax(xt[:, a_:b_], am_x, out=qx2[:, a_:b_]).scale
+          sh2 = pq.silu_mul_quantize_with_amax(gt_[:, a_:b_], ut_[:, a_:b_], am_h, out=qh2[:, a_:b_]).scale
+      bad += eqb(qx2, wq, "K1 split q", ctx) + eqb(sx2, ws, "K1 split s", ctx) + eqb(qh2, sq, "K1s split q", ctx) + eqb(sh2, ss, "K1s split s", ctx)
       w = Q.from_f32((1 + 0.2 * rng.standard_normal(cols)).astype(np.float32), code)
       eps = float(rng.choice([1e-6, 1e-5, 0.0]))
       nq, ns, nh, _ = C.rmsnorm_quant_rowwise(x, w, eps, code)
@@ -82,6 +95,11 @@ def run(budget, seed):
                               to_gpu(bv, code) if bv is not None else None, TD[code])
           bad += eqb(got, want, f"epilogue[{v or 'auto'}]", f"code={code} M={M2} N={N2} K={K2} bias={bv is not None}")
       _pqlib.set_option("PQ_FORCE_VARIANT", "")
+      # round 5: the same product with the activation codes STACKED in G K-slabs (ring tiles walk them in place, everything else takes the layout pass)
+      G2 = int(rng.choice([g_ for g_ in (1, 2, 4, 8) if (K2 // 128) % g_ == 0]))
+      stk = torch.from_numpy(np.ascontiguousarray(a.reshape(M2, G2, K2 // G2).transpose(1, 0, 2))).cuda()
+      got = pq.qlinear_s8_kslabs(stk, torch.from_numpy(xs2).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws2).cuda(), to_gpu(bv, code) if bv is not None else None, TD[code])
+      bad += eqb(got, want, "epilogue[kslabs]", f"code={code} M={M2} N={N2} K={K2} G={G2} bias={bv is not None}")
       n += 1
   print(f"fuzz_quant: {n} problems in {time.time() - t0:.0f} s, mismatches: {bad}")
   return n, bad

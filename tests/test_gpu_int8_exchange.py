@@ -112,7 +112,8 @@ def test_column_sharded_qlinear_on_a_column_sharded_input(pq, M, N, K, G, bias):
         assert torch.equal(y_r.view(torch.int16), y_ref[:, nb[r][0]:nb[r][1]].contiguous().view(torch.int16)), r
 
 
-@pytest.mark.parametrize("M,N,K,G,in_place", [(4096, 1024, 28672, 8, True), (1024, 1024, 8192, 8, True), (2048, 512, 4096, 4, True), (700, 1000, 1024, 2, True),
+@pytest.mark.parametrize("M,N,K,G,in_place", [(380, 484, 512, 4, True), (133, 633, 256, 2, True), (700, 300, 1024, 8, True), (2048, 1024, 2048, 8, True),      # slabs of ONE or two K-tiles (a fuzz find)
+                                             (4096, 1024, 28672, 8, True), (1024, 1024, 8192, 8, True), (2048, 512, 4096, 4, True), (700, 1000, 1024, 2, True),
                                              (256, 4096, 2048, 2, True), (4096, 4096, 4096, 4, False), (2048, 4096, 11008, 2, False), (16, 1024, 8192, 8, False), (37, 50, 384, 3, False),
                                              (300, 640, 960, 5, False)])
 def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
