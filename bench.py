@@ -73,6 +73,7 @@ def parse():
                     help="tp over RCCL: seconds EACH leg that drives the native exchange (libpq_rccl.so) may take; when one does not finish, the fastest verified leg "
                          "among those that did (the torch.distributed legs run first) is printed with \"native_exchange\": \"hung\" (a multi-GPU run is never lost to a hung collective)")
     ap.add_argument("--simulate-native-hang", action="store_true", help="tests: the native path never returns (the watchdog must print the safe line)")
+    ap.add_argument("--simulate-leg-hang", default="", help="tests: the named native leg never returns (the watchdog must print the best of the legs that finished before it)")
     return ap.parse_args()
 
 
@@ -1117,6 +1118,9 @@ def run_tp(args, world, rank, dev, dist):
         for leg in nat:
             order.append(leg.name)
             dog.arm(leg.name, args.native_timeout)
+            if args.simulate_leg_hang == leg.name:
+                while True:
+                    time.sleep(1.0)
             try:
                 results[leg.name] = run_leg(leg)
             except Exception as e:

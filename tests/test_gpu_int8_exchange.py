@@ -145,6 +145,33 @@ def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
         _lib.set_option("PQ_NO_KSLABS", "")
 
 
+@pytest.mark.parametrize("M,N,K,G,pad_k,pad_m", [(700, 300, 1024, 8, 16, 3), (4096, 1024, 8192, 8, 128, 0), (64, 96, 200, 2, 0, 0), (100, 130, 600, 3, 7, 2), (300, 4096, 2048, 2, 32, 1)])
+def test_kslabs_with_padded_slabs_through_the_c_abi(pq, M, N, K, G, pad_k, pad_m):
+    """the C-ABI's own generality: rows of a slab with a leading dimension wider than K / G, slabs further apart than M rows (a gather buffer with padding), widths that are
+    not a multiple of 16 bytes (byte-wise layout pass + the generic GEMM) — in place where a ring tile runs, through the layout pass otherwise; always pq_qlinear_s8's bits."""
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    xq = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).cuda()
+    xs, ws = (torch.rand(M, generator=g) * 0.01 + 1e-4).cuda(), (torch.rand(N, generator=g) * 0.01 + 1e-4).cuda()
+    kps = K // G
+    buf = torch.full((G, M + pad_m, kps + pad_k), 77, dtype=torch.int8, device="cuda")
+    buf[:, :M, :kps] = xq.reshape(M, G, kps).permute(1, 0, 2)
+    want = pq.qlinear_s8(xq, xs, wq, ws, None, torch.bfloat16)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    lda, stride = kps + pad_k, (M + pad_m) * (kps + pad_k)
+    # (the fast tiles need 16-byte aligned rows: an odd leading dimension or slab stride takes the layout pass, and the workspace query is told so through k_per_slab only —
+    # a direct caller with unaligned slabs sizes the workspace for the layout pass itself)
+    need = max(L.pq_qlinear_kslabs_workspace_bytes(M, N, K, kps), ((M * K + 255) // 256) * 256 + L.pq_qlinear_workspace_bytes(M, N, K))
+    wsp = torch.empty((need + 256,), dtype=torch.uint8, device="cuda")
+    rc = L.pq_qlinear_s8_kslabs(buf.data_ptr(), lda, stride, kps, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K,
+                                wsp.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.pq_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), want.view(torch.int16))
+
+
 def test_kslabs_argument_validation(pq):
     from protoquant_amd import _lib
     L = _lib.lib()

@@ -125,3 +125,16 @@ def test_bench_tp_line_says_native_ok_when_every_leg_finishes():
     line = json.loads(lines[0])
     assert "fallback" not in line and "hung_leg" not in line and line["native_exchange"] == "ok"
     assert line["torch_distributed_exchange_ms_per_step"] > 0 and NATIVE_LEGS <= set(line["legs"])
+
+
+def test_bench_tp_watchdog_keeps_the_native_legs_that_finished():
+    """a hang in the THIRD native leg: the line carries the two native legs that finished (verified, captured in the graph) beside the torch.distributed ones, the
+    headline is the fastest of them all, and the hung leg is named."""
+    r, lines = _bench_tp(["--simulate-leg-hang", "native_overlap2", "--native-timeout", "10"], "29567")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["native_exchange"] == "hung" and line["hung_leg"] == "native_overlap2" and "fallback" in line
+    assert set(line["legs"]) == {"torch_plain", "torch_transposed", "native_plain", "native_transposed"}
+    assert all(l["verified"] for l in line["legs"].values()) and line["verified"] is True
+    assert line["ms_per_step"] == min(l["ms_per_step"] for l in line["legs"].values())
