@@ -17,7 +17,8 @@ the same torch.distributed.run command as child processes before touching the GP
 over the ranks (N/G output channels each), the activation replicated, and ONE all-gather of the bf16 output shards per step rebuilds y[M, N]; the whole job is
 ONE M x N x K qlinear (strong scaling).  Every exchange form the repo holds is timed as a LEG by the same protocol (run_tp): torch.distributed's all-gather (rows /
 transposed shards) first, then libpq_rccl.so's plain gather + layout kernel, transposed shards (no layout pass) and 2 / 4 / 8 row blocks overlapped with the GEMM,
-each captured whole into the step's hipGraph and each under its own watchdog.  Every leg is VERIFIED (each rank compares the y it holds, bit for bit, with the
+each captured whole into the step's hipGraph and each under its own watchdog; over more than one rank every rank's work runs as a CHILD of a GPU-free supervisor
+process (supervise()) that prints the best verified line reported so far even if a native collective kills the worker.  Every leg is VERIFIED (each rank compares the y it holds, bit for bit, with the
 unsharded qlinear it computes itself); the headline `value` is the fastest verified leg, all legs are listed under `legs`.  The data-parallel figure (every rank its
 own batch, replicated weights, no collective) is reported under "dp"; `--mode dp` makes it the main line.
 
@@ -73,6 +74,9 @@ def parse():
                     help="tp over RCCL: seconds EACH leg that drives the native exchange (libpq_rccl.so) may take; when one does not finish, the fastest verified leg "
                          "among those that did (the torch.distributed legs run first) is printed with \"native_exchange\": \"hung\" (a multi-GPU run is never lost to a hung collective)")
     ap.add_argument("--simulate-native-hang", action="store_true", help="tests: the native path never returns (the watchdog must print the safe line)")
+    ap.add_argument("--supervise", action="store_true", help="tests: run the tp worker under its supervisor process also at 1 rank (always on at > 1 rank)")
+    ap.add_argument("--no-supervisor", action="store_true", help="tp over > 1 rank without the per-rank supervisor process (the worker prints its own line)")
+    ap.add_argument("--simulate-native-crash", action="store_true", help="tests: the worker kills itself (SIGSEGV) when it reaches the native exchange")
     ap.add_argument("--simulate-leg-hang", default="", help="tests: the named native leg never returns (the watchdog must print the best of the legs that finished before it)")
     return ap.parse_args()
 
@@ -1065,6 +1069,13 @@ def run_tp(args, world, rank, dev, dist):
             print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
             results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": False}
 
+    emit_marker("safe")                                  # (to the rank's supervisor: the torch.distributed legs are in)
+    if rank == 0:
+        emit_json(compose(), final=False)
+    if want_native and args.simulate_native_crash:
+        import signal
+        sys.stderr.flush()
+        os.kill(os.getpid(), signal.SIGSEGV)
     if want_native:
         def boot():
             from protoquant_amd.sharded import RcclColumnGather
@@ -1128,6 +1139,10 @@ def run_tp(args, world, rank, dev, dist):
                 results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": True}
             ok_everywhere = all_min("error" not in results[leg.name])   # (still under the leg's watchdog: a rank that raised is out of step with the others' collectives)
             dog.disarm()
+            if rank == 0:
+                with dog.lock:
+                    if not dog.done:
+                        emit_json(compose(), final=False)                # provisional: what the supervisor prints if a later leg kills this process
             if not ok_everywhere:                                       # stop trying native legs
                 shared["native_state"] = "failed"
                 break
@@ -1184,12 +1199,67 @@ def _claim_stdout():
         os.dup2(2, 1)
 
 
-def emit_json(obj):
+def _pipe_fd():
+    v = os.environ.get("PQ_BENCH_PIPE")
+    return int(v) if v else None
+
+
+def emit_json(obj, final=True):
+    """The ONE JSON line.  Under a supervisor (tp runs over more than one rank: supervise()) it goes to the supervisor's pipe as a record — provisional lines too,
+    so that the best line so far survives a worker that dies — and the supervisor prints the last one; otherwise straight to the original stdout."""
+    fd = _pipe_fd()
+    if fd is not None:
+        os.write(fd, (json.dumps({"final": bool(final), "line": obj}) + "\n").encode())
+        return
+    if not final:
+        return
     data = (json.dumps(obj) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(data.decode()); sys.stdout.flush()
     else:
         os.write(_JSON_FD, data)
+
+
+def emit_marker(name):
+    fd = _pipe_fd()
+    if fd is not None:
+        os.write(fd, (json.dumps({"marker": name}) + "\n").encode())
+
+
+def supervise(args):
+    """tp over more than one rank: THIS process (one per rank, started by torch.distributed.run) never touches the GPU.  It starts the real rank as a child — same
+    command, same environment, plus a pipe — and relays what the child reports: rank 0's worker sends every line it could print so far (after the torch.distributed
+    legs, after each native leg, the final one), every worker sends a marker once the torch.distributed legs are in.  However the child ends — normally, by its
+    watchdog, or KILLED by a fault inside a native collective (a segfault or a GPU memory fault cannot be caught inside the process) — rank 0's supervisor prints the
+    last line it holds ("native_exchange": "crashed" when the child died before its final line) and every supervisor whose child got as far as the safe legs exits 0:
+    the first multi-GPU run is one shot, and a verified torch.distributed line must survive anything the native exchange does."""
+    import subprocess
+    rfd, wfd = os.pipe()
+    env = dict(os.environ, PQ_BENCH_WORKER="1", PQ_BENCH_PIPE=str(wfd))
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, pass_fds=(wfd,))
+    os.close(wfd)
+    last, final, safe = None, False, False
+    with os.fdopen(rfd, "r") as pipe:
+        for raw in pipe:                       # ends when the child (and everything that inherited the pipe) is gone
+            try:
+                rec = json.loads(raw)
+            except ValueError:
+                continue
+            if "marker" in rec:
+                safe = safe or rec["marker"] == "safe"
+            elif "line" in rec:
+                last, final = rec["line"], bool(rec.get("final"))
+    rc = child.wait()
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0 and last is not None:
+        if not final:
+            last["native_exchange"] = "crashed"
+            last["fallback"] = (f"the rank's worker process ended (status {rc}) before its final line: this is the fastest verified leg among those that had finished — "
+                                "printed by the rank's supervisor process")
+        sys.stdout.write(json.dumps(last) + "\n"); sys.stdout.flush()
+    if rc != 0:
+        print(f"[bench] rank {rank}: worker ended with status {rc}" + ("; the line measured before it is kept" if safe else ""), file=sys.stderr)
+    sys.exit(0 if (rc == 0 or safe) else (rc if rc > 0 else 1))
 
 
 def self_launch(args):
@@ -1221,6 +1291,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return self_launch(args)
+    tp_ranks = args.workload == "qlinear" and args.mode != "dp" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.supervise and args.mode == "tp"))
+    if tp_ranks and not os.environ.get("PQ_BENCH_WORKER") and not args.no_supervisor:
+        return supervise(args)          # (before anything here has touched the GPU: `import torch` does not)
     _claim_stdout()
     if args.workload == "llama8b":
         assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"

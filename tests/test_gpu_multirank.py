@@ -138,3 +138,24 @@ def test_bench_tp_watchdog_keeps_the_native_legs_that_finished():
     assert set(line["legs"]) == {"torch_plain", "torch_transposed", "native_plain", "native_transposed"}
     assert all(l["verified"] for l in line["legs"].values()) and line["verified"] is True
     assert line["ms_per_step"] == min(l["ms_per_step"] for l in line["legs"].values())
+
+
+def test_bench_tp_supervisor_keeps_the_safe_line_when_the_worker_dies():
+    """tp runs over more than one rank put every rank's real work into a CHILD of a GPU-free supervisor process (bench.py: supervise): a fault inside a native
+    collective — a segfault, a GPU memory fault — cannot be caught in the process it kills, so the worker reports every line it could print so far through a pipe
+    and the supervisor prints the last one.  Here at one rank (--supervise), the worker killing itself with SIGSEGV when it reaches the native exchange: the line of
+    the verified torch.distributed legs comes out, marked "native_exchange": "crashed", and the exit status is 0."""
+    r, lines = _bench_tp(["--supervise", "--simulate-native-crash"], "29568")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["native_exchange"] == "crashed" and "fallback" in line and set(line["legs"]) == {"torch_plain", "torch_transposed"}
+    assert line["verified"] is True and line["value"] > 0 and line["config"]["headline_leg"] in line["legs"] and "worker ended with status" in r.stderr
+
+
+def test_bench_tp_supervisor_relays_the_final_line():
+    r, lines = _bench_tp(["--supervise"], "29569")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["native_exchange"] == "ok" and "fallback" not in line and NATIVE_LEGS <= set(line["legs"]) and line["verified"] is True
