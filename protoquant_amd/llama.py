@@ -111,3 +111,83 @@ def fuse_llama_layers(model: nn.Module, fuse_norms: bool = True, fuse_qkv: bool 
             layer.post_attention_layernorm = RMSNormQuant(layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
         n += 1
     return n
+
+
+# ---------------------------------------------------------------- BASELINE config 5: the same layers column-sharded over the ranks of one node
+class _ShardedInputProj(nn.Module):
+    """o_proj of a head-sharded attention: called by the stock attention code with THIS rank's heads of the attention output [..., H / G]; the int8-code exchange of
+    ColumnShardedQLinear.forward_sharded_input rebuilds the whole projection (this rank's output channels, then the all-gather of the output shards)."""
+
+    def __init__(self, sharded):
+        super().__init__()
+        self.sharded = sharded
+
+    def forward(self, x):
+        return self.sharded.forward_sharded_input(x)
+
+
+def _rows_of(lin: nn.Linear, lo: int, hi: int, device) -> nn.Linear:
+    sub = nn.Linear(lin.in_features, hi - lo, bias=lin.bias is not None, device=device, dtype=lin.weight.dtype)
+    with torch.no_grad():
+        sub.weight.copy_(lin.weight[lo:hi])
+        if lin.bias is not None:
+            sub.bias.copy_(lin.bias[lo:hi])
+    return sub
+
+
+def shard_llama_layers(model: nn.Module, world: int | None = None, rank: int | None = None, group=None, native=None, device=None,
+                       shard_lm_head: bool = True) -> int:
+    """BASELINE config 5 as a call site: every linear of every Llama-family decoder layer of `model` (still nn.Linear: call this INSTEAD of swap_linears) becomes this
+    rank's COLUMN shard of the int8 layer — north_star's scheme — and the stock attention / residual code keeps running unchanged, on this rank's heads:
+
+    * q / k / v: the rank's heads (q rows [r H/G, (r+1) H/G), k / v rows of its KV heads) as ONE fused local GEMM on the replicated, RMSNorm-fused int8 input; their
+      outputs are consumed by the rank's own attention heads — nothing is gathered (HF's attention infers the head count from the projection's width);
+    * o: the rank's output channels; its input — the rank's heads of the attention output — is exchanged as int8 codes (forward_sharded_input), its output shards are
+      all-gathered (the residual stream stays replicated);
+    * gate / up / down: ColumnShardedGatedMLP (int8-code exchange between them, all-gather of down's output shards);
+    * lm_head (shard_lm_head): column-sharded over the vocabulary, logits all-gathered.
+    The weights may live anywhere (CPU included): each layer's slices are copied to `device` (default: the current CUDA device) and quantised there, so a model
+    larger than one GPU's share can be sharded layer by layer.  native: an RcclColumnGather (libpq_rccl.so) — otherwise torch.distributed collectives over `group`.
+    Needs heads % G == 0, kv_heads % G == 0, intermediate % G == 0.  Returns the number of layers changed."""
+    import torch.distributed as dist
+
+    from .sharded import ColumnShardedGatedMLP, ColumnShardedQLinear, shard_bounds
+    if (world is None) != (rank is None):
+        raise ValueError("shard_llama_layers: pass world and rank together (or neither: the communicator's / process group's)")
+    if world is None:
+        world, rank = (native.world, native.rank) if native is not None else (dist.get_world_size(group), dist.get_rank(group))
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n = 0
+    for layer in model.modules():
+        attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+        if attn is None or mlp is None or not hasattr(layer, "input_layernorm") or not hasattr(layer, "post_attention_layernorm"):
+            continue
+        q, k, v, o = (getattr(attn, p, None) for p in ("q_proj", "k_proj", "v_proj", "o_proj"))
+        g, u, d = (getattr(mlp, p, None) for p in ("gate_proj", "up_proj", "down_proj"))
+        if not all(isinstance(p, nn.Linear) for p in (q, k, v, o, g, u, d)):
+            continue
+        hd = int(attn.head_dim)
+        nq, nkv = q.out_features // hd, k.out_features // hd
+        if nq % world or nkv % world or g.out_features % world or o.in_features != q.out_features:
+            raise ValueError(f"shard_llama_layers: {nq} heads / {nkv} KV heads / intermediate {g.out_features} do not split over {world} ranks")
+        ql, qh = rank * (nq // world) * hd, (rank + 1) * (nq // world) * hd
+        kl, kh = rank * (nkv // world) * hd, (rank + 1) * (nkv // world) * hd
+        attn.qkv_fused = _SharedFused(FusedQLinear.from_linears(_rows_of(q, ql, qh, device), _rows_of(k, kl, kh, device), _rows_of(v, kl, kh, device)))
+        attn.q_proj, attn.k_proj, attn.v_proj = (_FusedSlice(attn.qkv_fused, i) for i in range(3))
+        _install_qkv_hooks(attn)
+        ol, oh = shard_bounds(o.out_features, world, rank)
+        attn.o_proj = _ShardedInputProj(ColumnShardedQLinear(qlinear.from_linear(_rows_of(o, ol, oh, device)), o.out_features, group, native))
+        il, ih = shard_bounds(g.out_features, world, rank)
+        hl, hh = shard_bounds(d.out_features, world, rank)
+        layer.mlp = ColumnShardedGatedMLP(FusedQLinear.from_linears(_rows_of(g, il, ih, device), _rows_of(u, il, ih, device)), qlinear.from_linear(_rows_of(d, hl, hh, device)),
+                                          d.out_features, g.out_features, group, native, world, rank)
+        for name in ("input_layernorm", "post_attention_layernorm"):
+            nm = getattr(layer, name)
+            if _is_rmsnorm(nm):
+                setattr(layer, name, RMSNormQuant(nm.weight.to(device), nm.variance_epsilon))
+        n += 1
+    head = getattr(model, "lm_head", None)
+    if shard_lm_head and n and isinstance(head, nn.Linear):
+        lo, hi = shard_bounds(head.out_features, world, rank)
+        model.lm_head = ColumnShardedQLinear(qlinear.from_linear(_rows_of(head, lo, hi, device)), head.out_features, group, native)
+    return n

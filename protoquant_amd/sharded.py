@@ -456,9 +456,11 @@ class ColumnShardedGatedMLP(nn.Module):
         hq = self._encode(g2, u2, amax)
         return self._gather_codes(hq.int_data.reshape(g2.shape)), hq.scale
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x) -> torch.Tensor:
+        """x: the replicated activation [..., H], or its per-token QTensor (e.g. from rmsnorm_quantize)"""
         stacked, scale = self.hidden_codes(x)
-        y = self._gather_out(self._down(stacked, scale, x.dtype))
+        dtype = x.orig_dtype if isinstance(x, QTensor) else x.dtype
+        y = self._gather_out(self._down(stacked, scale, dtype))
         return y.reshape(*x.shape[:-1], self.hidden)
 
 

@@ -73,3 +73,21 @@ def test_fused_llama_layers_match_unfused_and_oracle(pq):
         b3 = clone(ids).logits
     assert torch.equal(b3.view(torch.int16), b2.view(torch.int16)) and len(calls) == 1      # ONE fused qkv GEMM per forward of that layer
     assert all(l.self_attn.qkv_fused._outs is None for l in model.model.layers)
+
+
+def test_llama_column_sharded_over_two_ranks():
+    """BASELINE config 5's scheme on a whole (small) Llama: shard_llama_layers over TWO ranks that share this GPU (gloo; RCCL refuses two ranks on one device) —
+    fused local q/k/v on the rank's heads, int8-code exchange in front of o and down, all-gather of the output shards — against the unsharded int8 model on every
+    rank: the MLP block and the o projection bit for bit, the logits bit for bit or to bf16 rounding (tests/llama_shard_worker.py)."""
+    pytest.importorskip("transformers")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "llama_shard_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r} " in o, f"rank {r} failed (rc {p.returncode}):\n{o[-3000:]}"

@@ -28,4 +28,18 @@ for M, N, K, reps in SHAPES:
             nbad += int((acc != ref_acc).sum().item()) + int((y.view(torch.int16) != ref_y.view(torch.int16)).sum().item())
     bad_total += nbad
     print(f"{M}x{N}x{K}: {reps} reps, mismatching elements: {nbad}")
+# round 5: the GEMM on STACKED activation codes (ring tiles walking K-slabs in place; the 4-slice fused split-K plan of the 70B `down` shard runs in the loop above)
+for M, N, K, G, reps in [(4096, 1024, 28672, 8, 60), (4096, 1024, 8192, 8, 300), (1024, 1024, 8192, 8, 400), (512, 4096, 4096, 4, 400), (380, 484, 512, 4, 800), (2048, 1024, 2048, 8, 400)]:
+    torch.manual_seed(M + N + K + G)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda"); b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda")
+    xs = torch.rand(M, device="cuda"); ws = torch.rand(N, device="cuda")
+    stk = a.reshape(M, G, K // G).permute(1, 0, 2).contiguous()
+    ref_y = pq.qlinear_s8(a, xs, b, ws, None, torch.bfloat16).clone()
+    nbad = 0
+    for i in range(reps):
+        y = pq.qlinear_s8_kslabs(stk, xs, b, ws, None, torch.bfloat16)
+        if i % 10 == 9 or i == reps - 1:
+            nbad += int((y.view(torch.int16) != ref_y.view(torch.int16)).sum().item())
+    bad_total += nbad
+    print(f"{M}x{N}x{K} stacked in {G} K-slabs: {reps} reps, mismatching elements: {nbad}")
 print("RACE SCREEN", "CLEAN" if bad_total == 0 else f"FAILED ({bad_total})")
