@@ -104,6 +104,31 @@ def main():
         y1 = m.forward_sharded_input(x[:, k0:k1])
         torch.cuda.synchronize()
         assert torch.equal(bits(y1), bits(y0)), (rank, "sharded input", M, N, K)
+    # a whole (small) Llama sharded over the ranks with the native exchange (llama.shard_llama_layers): logits against the unsharded int8 model on this rank
+    try:
+        import transformers as tr
+    except ImportError:
+        tr = None
+    if tr is not None:
+        import copy
+
+        from protoquant_amd.llama import fuse_llama_layers, shard_llama_layers
+        torch.manual_seed(0)
+        cfg = tr.LlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=8,
+                             max_position_embeddings=256, attn_implementation="eager")
+        base = tr.LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+        ref = copy.deepcopy(base).cuda()
+        pq.swap_linears(ref, fuse_gated_mlp=True)
+        fuse_llama_layers(ref)
+        sh = copy.deepcopy(base)
+        assert shard_llama_layers(sh, native=gather) == 2
+        sh = sh.cuda()
+        ids = torch.randint(0, 512, (2, 64), generator=torch.Generator().manual_seed(5)).cuda()
+        with torch.no_grad():
+            a, b = ref(ids).logits, sh(ids).logits
+        torch.cuda.synchronize()
+        diff = float((a.float() - b.float()).abs().max())
+        assert a.shape == b.shape and diff <= 0.02 * float(a.float().abs().max()), (rank, "sharded llama", diff)
     dist.barrier()
     gather.close()
     dist.destroy_process_group()
