@@ -547,7 +547,9 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     // Round 5, three runs on two boxes, weights from HBM (profiles/r05_ab_down_shard_forms.txt): ticket 99.1 - 99.5 us, ring tile 106.0 - 114.6, symmetric 93.4 — the
     // placement-independent ticket form is 6 - 13 % ahead, so it is planned again (with the caller's workspace; without one the ring tile runs).  Smaller grids
     // (2048 x 1024 x 28672: 85 us either way) stay with the ring tiles.
-    if (t256 > cus / 8 && t256 <= cus / 4 && K >= 16384 && K % 512 == 0) return 4;
+    // (the K threshold from tools/dispatch_audit.py on the round-5 build, profiles/r05_dispatch_audit_longk.txt: at K = 16384 the four slices LOSE 10 - 15 % to the ring
+    // tile on every such grid — 4096 x 1024 x 16384 68.8 against 62.8 us — at K = 28672 they win 2 - 6 %)
+    if (t256 > cus / 8 && t256 <= cus / 4 && K >= 24576 && K % 512 == 0) return 4;
     return 0;
 }
 
