@@ -87,7 +87,9 @@ int32_t pq_silu_mul_quant_rowwise(const void* g, int64_t ld_g, const void* u, in
  *   all-reduce(max) of amax_bits as uint32 over the ranks (pq_allreduce_max_u32 in pq_rccl.h, or any other exact max);
  *   pq_silu_mul_quant_rowwise_amax -> q[rows, cols_local] and scale[rows] against the GLOBAL amax (h is recomputed: S1-S5 are deterministic)
  * give every rank the column block of the unsharded kernel's codes and the unsharded scale vector, bit for bit; the int8 blocks (1 byte per
- * element instead of 2 x 2 bytes of bf16 g and u) are what travels.  Same numerics, layouts and argument meaning as pq_silu_mul_quant_rowwise. */
+ * element instead of 2 x 2 bytes of bf16 g and u) are what travels.  Same numerics, layouts and argument meaning as pq_silu_mul_quant_rowwise.
+ * Precondition of the encode half: amax_bits[r] >= the row's local amax (true of any max that includes this block) — the exact encode does not clamp, a smaller
+ * amax makes codes wrap. */
 int32_t pq_silu_mul_rowamax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
                             uint32_t* amax_bits, void* stream);
 int32_t pq_silu_mul_quant_rowwise_amax(const void* g, int64_t ld_g, const void* u, int64_t ld_u, int32_t dtype, int64_t rows, int64_t cols,
