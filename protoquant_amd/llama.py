@@ -135,9 +135,25 @@ def _rows_of(lin: nn.Linear, lo: int, hi: int, device) -> nn.Linear:
     return sub
 
 
+def _q_rows(mod, lo: int, hi: int, device) -> qlinear:
+    """rows [lo, hi) of a projection as a qlinear on `device`: an nn.Linear's slice is quantised there; a qlinear's int8 codes, scales and bias are SLICED (per-channel
+    quantisation is row-local: the slice of the codes is the codes of the slice) — an int8 checkpoint is sharded without its bf16 weights ever existing."""
+    if isinstance(mod, qlinear):
+        bias = mod.bias[lo:hi].to(device).contiguous() if mod.bias is not None else None
+        dt = mod.bias.dtype if mod.bias is not None else torch.bfloat16
+        qt = QTensor(mod.wq[lo:hi].to(device).contiguous(), mod.ws[lo:hi].to(device).contiguous(), 1, dt, torch.Size((hi - lo, mod.in_features)))
+        return qlinear.from_qtensor(qt, bias)
+    return qlinear.from_linear(_rows_of(mod, lo, hi, device))
+
+
+def _is_proj(m) -> bool:
+    return isinstance(m, (nn.Linear, qlinear))
+
+
 def shard_llama_layers(model: nn.Module, world: int | None = None, rank: int | None = None, group=None, native=None, device=None,
                        shard_lm_head: bool = True) -> int:
-    """BASELINE config 5 as a call site: every linear of every Llama-family decoder layer of `model` (still nn.Linear: call this INSTEAD of swap_linears) becomes this
+    """BASELINE config 5 as a call site: every linear of every Llama-family decoder layer of `model` — nn.Linear (call this INSTEAD of swap_linears) or already a
+    qlinear / GatedMLP (a model loaded from an int8 checkpoint, or after swap_linears: codes and scales are sliced, nothing is re-quantised) — becomes this
     rank's COLUMN shard of the int8 layer — north_star's scheme — and the stock attention / residual code keeps running unchanged, on this rank's heads:
 
     * q / k / v: the rank's heads (q rows [r H/G, (r+1) H/G), k / v rows of its KV heads) as ONE fused local GEMM on the replicated, RMSNorm-fused int8 input; their
@@ -163,8 +179,15 @@ def shard_llama_layers(model: nn.Module, world: int | None = None, rank: int | N
         if attn is None or mlp is None or not hasattr(layer, "input_layernorm") or not hasattr(layer, "post_attention_layernorm"):
             continue
         q, k, v, o = (getattr(attn, p, None) for p in ("q_proj", "k_proj", "v_proj", "o_proj"))
-        g, u, d = (getattr(mlp, p, None) for p in ("gate_proj", "up_proj", "down_proj"))
-        if not all(isinstance(p, nn.Linear) for p in (q, k, v, o, g, u, d)):
+        if isinstance(mlp, GatedMLP):          # swap_linears(fuse_gated_mlp=True): gate and up are the two row blocks of one fused weight
+            I_ = mlp.gate_up.splits[0]
+            gu_w = mlp.gate_up
+            mk = lambda a, b: qlinear.from_qtensor(QTensor(gu_w.wq[a:b], gu_w.ws[a:b], 1, torch.bfloat16, torch.Size((b - a, gu_w.in_features))),      # noqa: E731
+                                                   gu_w.bias[a:b] if gu_w.bias is not None else None)
+            g, u, d = mk(0, I_), mk(I_, 2 * I_), mlp.down
+        else:
+            g, u, d = (getattr(mlp, p, None) for p in ("gate_proj", "up_proj", "down_proj"))
+        if not all(_is_proj(p) for p in (q, k, v, o, g, u, d)):
             continue
         hd = int(attn.head_dim)
         nq, nkv = q.out_features // hd, k.out_features // hd
@@ -172,14 +195,14 @@ def shard_llama_layers(model: nn.Module, world: int | None = None, rank: int | N
             raise ValueError(f"shard_llama_layers: {nq} heads / {nkv} KV heads / intermediate {g.out_features} do not split over {world} ranks")
         ql, qh = rank * (nq // world) * hd, (rank + 1) * (nq // world) * hd
         kl, kh = rank * (nkv // world) * hd, (rank + 1) * (nkv // world) * hd
-        attn.qkv_fused = _SharedFused(FusedQLinear.from_linears(_rows_of(q, ql, qh, device), _rows_of(k, kl, kh, device), _rows_of(v, kl, kh, device)))
+        attn.qkv_fused = _SharedFused(FusedQLinear([_q_rows(q, ql, qh, device), _q_rows(k, kl, kh, device), _q_rows(v, kl, kh, device)]))
         attn.q_proj, attn.k_proj, attn.v_proj = (_FusedSlice(attn.qkv_fused, i) for i in range(3))
         _install_qkv_hooks(attn)
         ol, oh = shard_bounds(o.out_features, world, rank)
-        attn.o_proj = _ShardedInputProj(ColumnShardedQLinear(qlinear.from_linear(_rows_of(o, ol, oh, device)), o.out_features, group, native))
+        attn.o_proj = _ShardedInputProj(ColumnShardedQLinear(_q_rows(o, ol, oh, device), o.out_features, group, native))
         il, ih = shard_bounds(g.out_features, world, rank)
         hl, hh = shard_bounds(d.out_features, world, rank)
-        layer.mlp = ColumnShardedGatedMLP(FusedQLinear.from_linears(_rows_of(g, il, ih, device), _rows_of(u, il, ih, device)), qlinear.from_linear(_rows_of(d, hl, hh, device)),
+        layer.mlp = ColumnShardedGatedMLP(FusedQLinear([_q_rows(g, il, ih, device), _q_rows(u, il, ih, device)]), _q_rows(d, hl, hh, device),
                                           d.out_features, g.out_features, group, native, world, rank)
         for name in ("input_layernorm", "post_attention_layernorm"):
             nm = getattr(layer, name)
@@ -187,7 +210,7 @@ def shard_llama_layers(model: nn.Module, world: int | None = None, rank: int | N
                 setattr(layer, name, RMSNormQuant(nm.weight.to(device), nm.variance_epsilon))
         n += 1
     head = getattr(model, "lm_head", None)
-    if shard_lm_head and n and isinstance(head, nn.Linear):
+    if shard_lm_head and n and _is_proj(head):
         lo, hi = shard_bounds(head.out_features, world, rank)
-        model.lm_head = ColumnShardedQLinear(qlinear.from_linear(_rows_of(head, lo, hi, device)), head.out_features, group, native)
+        model.lm_head = ColumnShardedQLinear(_q_rows(head, lo, hi, device), head.out_features, group, native)
     return n

@@ -34,9 +34,16 @@ def main():
     sh = copy.deepcopy(base)
     assert shard_llama_layers(sh) == 2
     sh = sh.cuda()                                                      # embeddings, final norm, rotary tables (the sharded linears are there already)
+    # the same sharding from an ALREADY-QUANTISED model (an int8 checkpoint / after swap_linears): the int8 codes and scales are sliced, nothing is re-quantised
+    sh_q = copy.deepcopy(base).cuda()
+    pq.swap_linears(sh_q, fuse_gated_mlp=True)
+    assert shard_llama_layers(sh_q) == 2
     ids = torch.randint(0, 512, (2, 64), generator=torch.Generator().manual_seed(5)).cuda()
     with torch.no_grad():
         a, b = ref(ids).logits, sh(ids).logits
+        b_q = sh_q(ids).logits
+    assert torch.equal(b.view(torch.int16), b_q.view(torch.int16)), "sharding a quantised model differs from sharding its float original"
+    with torch.no_grad():
         # the MLP block alone, on the same replicated input: bit-identical by construction (every collective in it is exact)
         x = (torch.randn(2, 40, 512, generator=torch.Generator().manual_seed(6)) * 1.5).to(torch.bfloat16).cuda()
         hn_r, hn_s = ref.model.layers[0].post_attention_layernorm(x), sh.model.layers[0].post_attention_layernorm(x)
