@@ -587,7 +587,16 @@ def run_llama70b_shard(args):
         XG = 153e9
         hop_bf16 = 2 * (2.0 * M * ig) / XG + 2 * 2 * (2.0 * M * I * 2) / 5e12       # gather of the bf16 gate and up shards (one link per peer, all links at once) + their layout passes
         hop_int8 = (4.0 * M) / XG + (1.0 * M * ig) / XG                             # all-reduce of M amax patterns (latency-bound in practice) + gather of the int8 blocks; no layout pass
+        # a layer's exchanges, modelled per rank (its shard over one direct link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s): the plain composition
+        # gathers every projection's bf16 output (q/k/v, o, gate and up, down); the int8 form gathers nothing after q/k/v (the rank's own heads consume them), int8 codes
+        # in front of o and down, and the bf16 outputs of o and down (the replicated residual stream)
+        link = lambda nbytes: nbytes / XG * 1e6      # noqa: E731
+        ex_bf16 = link(2.0 * M * (H + 2 * KVD) / G) + link(2.0 * M * H / G) + link(2.0 * M * 2 * I / G) + link(2.0 * M * H / G) \
+            + 2 * 2.0 * M * ((H + 2 * KVD) + H + 2 * I + H) / 5e12 * 1e6
+        ex_int8 = link(1.0 * M * H / G) + link(2.0 * M * H / G) + link(1.0 * M * I / G) + link(2.0 * M * H / G) + 2 * link(4.0 * M) + 2 * 2 * 2.0 * M * H / 5e12 * 1e6
         int8x = {"ms_per_step": round(di * 1e3, 3), "value": round(ops / di / 1e12, 2), "unit": "TOPS", "us_per_layer": round((di - 0) / L * 1e6, 1),
+                 "modelled_exchange_us_per_layer": {"bf16_gather_of_every_output": round(ex_bf16, 1), "int8_code_exchange": round(ex_int8, 1),
+                                                    "model": "per rank: its shard over one direct xGMI link per peer at 153 GB/s, all 7 links at once, + layout passes at 5 TB/s; NOT measured, not overlapped with compute"},
                  "what": "per layer: rmsnorm x2, qkv shard, row amax + encode of the LOCAL 1024 attention features, o shard on the stacked int8 blocks, gate+up shard, "
                          "silu*mul row amax + encode on the LOCAL 3584 channels, down shard on the stacked int8 blocks (slabs walked in place)",
                  "modelled_gate_up_to_down_hop_us": {"bf16_gather_of_gate_and_up_plus_layout": round(hop_bf16 * 1e6, 1), "int8_code_exchange": round(hop_int8 * 1e6, 1),
