@@ -1235,6 +1235,29 @@ def emit_marker(name):
         os.write(fd, (json.dumps({"marker": name}) + "\n").encode())
 
 
+def supervisor_verdict(records, rc):
+    """What a rank's supervisor does with what its worker reported (raw pipe lines) and how the worker ended: (the line to print or None, the exit status, whether the
+    worker got past the safe legs).  The last line record wins; a line that is not the worker's final one is marked "native_exchange": "crashed"; a worker that died
+    after the torch.distributed legs were in does not fail the rank."""
+    last, final, safe = None, False, False
+    for raw in records:
+        try:
+            rec = json.loads(raw)
+        except ValueError:
+            continue                           # (a record cut short by the worker's death)
+        if not isinstance(rec, dict):
+            continue
+        if "marker" in rec:
+            safe = safe or rec["marker"] == "safe"
+        elif rec.get("line") is not None:
+            last, final = rec["line"], bool(rec.get("final"))
+    if last is not None and not final:
+        last["native_exchange"] = "crashed"
+        last["fallback"] = (f"the rank's worker process ended (status {rc}) before its final line: this is the fastest verified leg among those that had finished — "
+                            "printed by the rank's supervisor process")
+    return last, (0 if (rc == 0 or safe) else (rc if rc > 0 else 1)), safe
+
+
 def supervise(args):
     """tp over more than one rank: THIS process (one per rank, started by torch.distributed.run) never touches the GPU.  It starts the real rank as a child — same
     command, same environment, plus a pipe — and relays what the child reports: rank 0's worker sends every line it could print so far (after the torch.distributed
@@ -1247,28 +1270,16 @@ def supervise(args):
     env = dict(os.environ, PQ_BENCH_WORKER="1", PQ_BENCH_PIPE=str(wfd))
     child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, pass_fds=(wfd,))
     os.close(wfd)
-    last, final, safe = None, False, False
     with os.fdopen(rfd, "r") as pipe:
-        for raw in pipe:                       # ends when the child (and everything that inherited the pipe) is gone
-            try:
-                rec = json.loads(raw)
-            except ValueError:
-                continue
-            if "marker" in rec:
-                safe = safe or rec["marker"] == "safe"
-            elif "line" in rec:
-                last, final = rec["line"], bool(rec.get("final"))
+        records = list(pipe)                   # ends when the child (and everything that inherited the pipe) is gone
     rc = child.wait()
     rank = int(os.environ.get("RANK", "0"))
-    if rank == 0 and last is not None:
-        if not final:
-            last["native_exchange"] = "crashed"
-            last["fallback"] = (f"the rank's worker process ended (status {rc}) before its final line: this is the fastest verified leg among those that had finished — "
-                                "printed by the rank's supervisor process")
-        sys.stdout.write(json.dumps(last) + "\n"); sys.stdout.flush()
+    line, code, safe = supervisor_verdict(records, rc)
+    if rank == 0 and line is not None:
+        sys.stdout.write(json.dumps(line) + "\n"); sys.stdout.flush()
     if rc != 0:
         print(f"[bench] rank {rank}: worker ended with status {rc}" + ("; the line measured before it is kept" if safe else ""), file=sys.stderr)
-    sys.exit(0 if (rc == 0 or safe) else (rc if rc > 0 else 1))
+    sys.exit(code)
 
 
 def self_launch(args):
