@@ -169,10 +169,22 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
 
 /* pq_qlinear_s8 on STACKED activation codes: K-slab s — the columns [s * k_per_slab, (s + 1) * k_per_slab) of the logical a[M, K] — is the row-major
  * block a + s * slab_stride with leading dimension lda (what an all-gather of the ranks' int8 column blocks [M, K / G] leaves: slab_stride = M * K / G).
- * An integer sum has no order: the result is pq_qlinear_s8's on the row-major matrix, bit for bit.  Where the planner picks the 128 x 128 ring tile (the
- * Llama-70B `down` shard 4096 x 1024 x 28672 does) its loaders walk the slabs in place — no layout pass, no workspace; any other shape takes ONE layout pass
- * into `workspace` (M * K bytes read and written) and then pq_qlinear_s8.  K % k_per_slab == 0; workspace per pq_qlinear_kslabs_workspace_bytes (256-byte aligned). */
+ * An integer sum has no order: the result is pq_qlinear_s8's on the row-major matrix, bit for bit.  Three ways, in this order:
+ *   (1) where pq_qlinear_s8 would run the fused split-K of the 256 x 256 tile (the Llama-70B `down` shard 4096 x 1024 x 28672: four K-slices) AND a workspace of
+ *       the hand-over's size is passed AND the slices cover whole slabs (or a slab holds whole slices; >= 512 columns per slab): that kernel walks the slabs in
+ *       place — its K-loop's activation cursor jumps at the slab boundaries (round 6);
+ *   (2) where the planner picks a ring tile (128 x 128, 64 x 128, 64 x 64: the Llama-70B `o` shard, and the `down` shard when no workspace comes): its loaders walk
+ *       the slabs in place — no layout pass, no workspace;
+ *   (3) any other shape: ONE layout pass into `workspace` (M * K bytes read and written), then pq_qlinear_s8.
+ * K % k_per_slab == 0.  Workspace (256-byte aligned): pq_qlinear_kslabs_workspace_bytes is the size that is ALWAYS enough (way 3's: it knows neither base nor
+ * strides); pq_qlinear_kslabs_workspace_bytes_for decides on the very operands of the call (only their alignment is looked at, nothing is read): way 1's hand-over
+ * slabs, 0 for way 2, way 3's otherwise.  A workspace smaller than way 1 needs is not an error: ways 2 / 3 follow. */
 size_t pq_qlinear_kslabs_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t k_per_slab);
+size_t pq_qlinear_kslabs_workspace_bytes_for(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const int8_t* b, int64_t ldb,
+                                             int64_t M, int64_t N, int64_t K);
+/* which way a call with these operands and a workspace of workspace_bytes takes: "in place: fused split-K x4", "in place: ring128", "layout pass", ... (static string) */
+const char* pq_kslabs_way_name(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const int8_t* b, int64_t ldb,
+                               int64_t M, int64_t N, int64_t K, size_t workspace_bytes);
 int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const float* a_scale, const int8_t* b, int64_t ldb,
                              const float* b_scale, const void* bias, void* y, int64_t ldy, int32_t out_dtype, int64_t M, int64_t N, int64_t K,
                              void* workspace, size_t workspace_bytes, void* stream);

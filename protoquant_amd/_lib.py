@@ -20,7 +20,7 @@ EXPORTS = (
     "pq_gemm_s8s8s32", "pq_qlinear_s8", "pq_qlinear_workspace_bytes", "pq_gemm_variant_name",
     "pq_selftest_fast_quotient", "pq_selftest_half_encode", "pq_selftest_silu_short", "pq_qlinear_dyn", "pq_qlinear_dyn_workspace_bytes", "pq_silu_mul_quant_rowwise",
     "pq_rmsnorm_quant_rowwise", "pq_set_option", "pq_qlinear_s8_t", "pq_qlinear_t_workspace_bytes",
-    "pq_silu_mul_rowamax", "pq_silu_mul_quant_rowwise_amax", "pq_qlinear_s8_kslabs", "pq_qlinear_kslabs_workspace_bytes",
+    "pq_silu_mul_rowamax", "pq_silu_mul_quant_rowwise_amax", "pq_qlinear_s8_kslabs", "pq_qlinear_kslabs_workspace_bytes", "pq_qlinear_kslabs_workspace_bytes_for", "pq_kslabs_way_name",
     "pq_quant_rowamax", "pq_quant_rowwise_amax",
 )
 
@@ -76,6 +76,10 @@ def lib() -> ctypes.CDLL:
     L.pq_quant_rowwise_amax.argtypes = [vp, i32, i64, i64, i64, vp, vp, i64, vp, vp]
     L.pq_qlinear_kslabs_workspace_bytes.restype = sz
     L.pq_qlinear_kslabs_workspace_bytes.argtypes = [i64, i64, i64, i64]
+    L.pq_qlinear_kslabs_workspace_bytes_for.restype = sz
+    L.pq_qlinear_kslabs_workspace_bytes_for.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, i64]
+    L.pq_kslabs_way_name.restype = ctypes.c_char_p
+    L.pq_kslabs_way_name.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, i64, sz]
     L.pq_qlinear_s8_kslabs.restype = i32
     L.pq_qlinear_s8_kslabs.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64, i64, vp, sz, vp]
     L.pq_silu_mul_quant_rowwise.restype = i32

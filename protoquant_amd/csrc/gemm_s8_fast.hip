@@ -75,10 +75,16 @@ __host__ __device__ constexpr size_t fsk_counter_bytes(int ntiles, int kslices) 
 // part it kept and runs the epilogue of that part (fsk_sym2_asm / fsk_sym4_asm): no idle CU, 1 / S of an epilogue each.  The wait is for workgroups that may NOT
 // be running (another fused split-K launch on a second stream can hold the CUs their partners need): these forms are opt-in (PQ_FSK_SYMMETRIC=1, pq_hip.h); the default
 // is the ticket form above (FSK = 1), which never waits for a workgroup that has not finished its K-loop.
-template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4, int FSK = 0>   // ABL: compile-time ablation (0 = product)
+// KSL (FSK = 1 only; round 6): the activation operand arrives STACKED as an all-gather of int8 column blocks leaves it, [G][M][K / G] (pq_qlinear_s8_kslabs) — K-tile kt of
+// the whole K lives in slab kt / q_tps at q_slab_stride bytes per slab, ldx = the slab's row length.  A slice's K range starts inside one slab and may run over several:
+// the asm K-loop's activation cursor jumps at every slab boundary (kloop_p3_asm<5>: slab_step in tools/gen_kloop_asm.py).  The launcher guarantees that the slices
+// cover whole slabs or that a slab holds whole slices, and at least four K-tiles per slab (the HIP-coded prologue and tile 0 request the slice's first three).
+// Integer sums have no order: the bits of the row-major GEMM, without the layout pass.
+template <int OUT, int ABL, int TM = 256, int TN = 256, bool LC = false, bool P3 = false, int ASMV = 0, int NCW = 4, int FSK = 0, bool KSL = false>   // ABL: compile-time ablation (0 = product)
 __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 : 2) void gemm_s8_sp256(const int8_t* __restrict__ X, int64_t ldx,
                                                         const int8_t* __restrict__ W, int64_t ldw, EpiArgs epi,
-                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices) {
+                                                        int M, int N, int K, int tiles_m, int tiles_n, int dbg, unsigned long long* stamps, int kslices,
+                                                        int64_t q_slab_stride = 0, int q_tps = 0) {
     // ablation bits (dev builds only): 1 skip DMA, 2 skip LDS reads, 4 skip MFMA, 8 skip epilogue, 16 direct epilogue
     constexpr bool DBG = ABL != 0;
     constexpr bool no_dma = ABL & 1, no_lds = ABL & 2, no_mma = ABL & 4, no_epi = ABL & 8, direct_epi = ABL & 16;
@@ -117,6 +123,7 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     static_assert(!P3 || (TM == 256 && TN == 256 && !LC), "split rings: 256 x 256 tile only");
     static_assert(ASMV == 0 || (P3 && (ABL & ~(1024 | 8 | 2048)) == 0), "asm K-loop: split-ring tile only (dev builds: with stamps, and the epilogue ablations)");
     static_assert(FSK == 0 || (P3 && ASMV != 0 && ABL == 0 && OUT != OUT_I32), "fused split-K: the asm split-ring kernel with a dequantising epilogue");
+    static_assert(!KSL || FSK == 1, "K-slab walk: the ticket form of the fused split-K only");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     static_assert(NCW == 4 || (LC && NCW == 8), "consumer waves");
@@ -132,7 +139,10 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
     // accumulators to slab s of the output buffer; a separate kernel sums the slabs and applies the epilogue.
     const int ntiles_all = tiles_m * tiles_n;
     const int kslice = FSK >= 2 ? ((int)blockIdx.x & (FSK - 1)) : (int)blockIdx.x / ntiles_all;
-    const int Ks = K / kslices;                       // bytes of K per slice (a multiple of FBK)
+    // K-tiles of this slice: the K / FBK tiles are dealt as evenly as they go (round 6: the first (K / FBK) % kslices slices take one more — three slices of a 64-tile K)
+    const int nt_base = (K / FBK) / kslices, nt_rem = (K / FBK) - nt_base * kslices;
+    const int kt_start = kslice * nt_base + (kslice < nt_rem ? kslice : nt_rem);
+    const int Ks = (nt_base + (kslice < nt_rem ? 1 : 0)) * FBK;      // bytes of K of this slice (a multiple of FBK)
     int t;
     if constexpr (FSK >= 2) {      // partners S p .. S p + S - 1 (neighbouring XCDs); every (8 / S)-th partner set shares those XCDs: a contiguous run of tiles for them
         constexpr int NGX = 8 / FSK;
@@ -179,8 +189,14 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
             offQ[h][jj] = (uint32_t)ml * (uint32_t)ldx + src_chunk * 16;
         }
     }
-    const int8_t* gP = W + (int64_t)n0 * ldw + (int64_t)kslice * Ks;   // uniform; advanced by FBK per staged K-tile
-    const int8_t* gQ = X + (int64_t)m0 * ldx + (int64_t)kslice * Ks;
+    const int8_t* gP = W + (int64_t)n0 * ldw + (int64_t)kt_start * FBK;   // uniform; advanced by FBK per staged K-tile
+    const int8_t* gQ = X + (int64_t)m0 * ldx + (int64_t)kt_start * FBK;
+    uint32_t qs_cnt = 0x7fffffffu;          // KSL: K-tiles whose activation pieces are still to be requested from the current slab, counted from the asm loop's first tile, minus one
+    if constexpr (KSL) {
+        const int kt0 = kt_start, sl0 = kt0 / q_tps, in0 = kt0 - sl0 * q_tps;
+        gQ = X + (int64_t)m0 * ldx + (int64_t)sl0 * q_slab_stride + (int64_t)in0 * FBK;
+        if (Ks / FBK > q_tps - in0) qs_cnt = (uint32_t)__builtin_amdgcn_readfirstlane(q_tps - in0 - 4);      // (three tiles are requested before the statement: launcher, q_tps - in0 >= 4)
+    }
     // K walk of the loader / consumer form (round 4; `dbg` carries the chunk length in K-tiles for that form, 0 = the plain walk): the up-to-4 workgroups of a band
     // that stream one weight panel (neighbours on one XCD, started together) walk each chunk of K-tiles from different starting points and wrap inside the chunk —
     // gemm_s8_ring.hip, "K ROTATION in chunks".  Integer sums: same bits.
@@ -503,6 +519,12 @@ __global__ __launch_bounds__((LC && NCW == 8) ? 768 : 512, (LC && NCW == 8) ? 3 
                     }
                 kloop_p3_asm<ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQd, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
                                    0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
+            } else if constexpr (KSL) {
+                const int64_t qdelta = q_slab_stride - (int64_t)q_tps * FBK;
+                kloop_p3_asm<5>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
+                                0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2),
+                                qs_cnt, (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qdelta), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qdelta >> 32)),
+                                (uint32_t)__builtin_amdgcn_readfirstlane(q_tps - 1));
             } else
             kloop_p3_asm<FSK != 0 ? 4 : ASMV>(acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, (uint32_t)(NT - 4), smem_base + (uint32_t)piece_off,
                                0u, ssrc, smem_base + (uint32_t)w * 1024u, do_scales, (uint32_t)(wave >> 2));
@@ -990,13 +1012,25 @@ size_t fsk_workspace_bytes(int64_t M, int64_t N, int kslices) {
     return fsk_counter_bytes((int)ntiles, kslices) + (size_t)ntiles * (size_t)(kslices - 1) * (size_t)(256 * 256 * 4);
 }
 // (returns false, WITHOUT launching, when the flags could not be zeroed: the kernel's waits would never end on flags that hold garbage)
+// can the ticket form walk this stacked activation operand in place?  (slices cover whole slabs, or a slab holds whole slices; >= 4 K-tiles per slab; the ticket form)
+bool fsk_kslabs_ok(int64_t K, int64_t k_per_slab, int kslices) {
+    if (k_per_slab <= 0 || k_per_slab % FBK != 0 || K % k_per_slab != 0 || k_per_slab < 4 * FBK || kslices < 2 || K % ((int64_t)kslices * FBK) != 0) return false;
+    if (opt().fsk_symmetric || opt().fsk_coop) return false;
+    const int64_t nslabs = K / k_per_slab;
+    return nslabs % kslices == 0 || kslices % nslabs == 0;
+}
 template <int OUT>
 bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
-                     int kslices, void* workspace, hipStream_t st) {
+                     int kslices, void* workspace, hipStream_t st, int64_t a_slab_stride, int64_t a_k_per_slab) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     if (hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st) != hipSuccess) return false;   // tickets and ready counts / flags
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
+    if (a_k_per_slab > 0 && a_k_per_slab < K) {      // stacked activation codes walked in place (the caller checked fsk_kslabs_ok)
+        gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1, true><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, opt().fsk_fenced ? 1 : 0, ws, kslices,
+                                                                                     a_slab_stride, (int)(a_k_per_slab / FBK));
+        return true;
+    }
     // the SYMMETRIC exchanges WAIT for partner workgroups: they need every workgroup of the launch resident at once.  A COOPERATIVE launch (round 5) is the runtime's own
     // guarantee of exactly that — hipLaunchCooperativeKernel either places the whole grid together (and serialises cooperative launches of the device against each other) or
     // returns an error — so with PQ_FSK_COOP=1 the symmetric kernels go out that way, and any error (grid too large for the CUs this queue may use, a capture
@@ -1024,18 +1058,19 @@ bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
         gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, opt().fsk_fenced ? 1 : 0, ws, kslices);
     return true;
 }
-template bool launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
-template bool launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
-template bool launch_gemm_fsk<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template bool launch_gemm_fsk<PQ_BF16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t, int64_t, int64_t);
+template bool launch_gemm_fsk<PQ_FP16>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t, int64_t, int64_t);
+template bool launch_gemm_fsk<PQ_F32>(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t, int64_t, int64_t);
 
 // ---- split-K: S K-slices of the int32 GEMM into S slabs of `slabs` (each [M, N], ld = N), then one pass that sums
 // the slabs (exact) and applies QSPEC E1-E4.  Doubles/quadruples the busy CUs for small-MN / long-K problems.
 template <int TM>
 void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, int32_t* slabs,
-                            int64_t M, int64_t N, int64_t K, int kslices, hipStream_t st) {
+                            int64_t M, int64_t N, int64_t K, int kslices, hipStream_t st, int nxcd) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + FT - 1) / FT);
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     EpiArgs epi{nullptr, nullptr, nullptr, slabs, N, 0};
+    epi.nxcd = nxcd;                  // (the caller's: the XCD count of the device the launch goes to — ADVICE r5)
     if constexpr (TM == 256) {      // slices of at least five K-tiles: the split-ring tile with the asm K-loop
         if (opt().sp256_p3 && opt().sp256_asm == 1 && K / kslices >= 5 * FBK) {
             gemm_s8_sp256<OUT_I32, 0, 256, 256, false, true, 1><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
@@ -1044,8 +1079,8 @@ void launch_gemm_splitk_i32(const int8_t* A, int64_t lda, const int8_t* B, int64
     }
     gemm_s8_sp256<OUT_I32, 0, TM><<<grid, block, 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, 0, nullptr, kslices);
 }
-template void launch_gemm_splitk_i32<256>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
-template void launch_gemm_splitk_i32<128>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
+template void launch_gemm_splitk_i32<256>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t, int);
+template void launch_gemm_splitk_i32<128>(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t, int);
 
 template <int OUT>
 __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const int32_t* __restrict__ slabs, int kslices, int64_t M, int64_t N,

@@ -23,9 +23,10 @@ template <int OUT> void launch_gemm_ring128(const int8_t*, int64_t, const int8_t
 template <int OUT> void launch_gemm_ringt(int, const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
 template <int OUT> void launch_gemm_skinny(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, hipStream_t);
 bool gemm_fast_eligible(const int8_t*, int64_t, const int8_t*, int64_t, int64_t, int64_t, int64_t);
-template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t);
+template <int TM> void launch_gemm_splitk_i32(const int8_t*, int64_t, const int8_t*, int64_t, int32_t*, int64_t, int64_t, int64_t, int, hipStream_t, int nxcd);
 template <int OUT> void launch_splitk_reduce(const int32_t*, int, int64_t, int64_t, const EpiArgs&, hipStream_t);
-template <int OUT> bool launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t);
+template <int OUT> bool launch_gemm_fsk(const int8_t*, int64_t, const int8_t*, int64_t, const EpiArgs&, int64_t, int64_t, int64_t, int, void*, hipStream_t, int64_t a_slab_stride = 0, int64_t a_k_per_slab = 0);
+bool fsk_kslabs_ok(int64_t K, int64_t k_per_slab, int kslices);
 size_t fsk_workspace_bytes(int64_t, int64_t, int);
 void set_stamp_buffer(unsigned long long*);
 void launch_fast_quotient_check(const uint32_t*, const uint32_t*, int64_t, unsigned long long*, hipStream_t);
@@ -536,7 +537,8 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     const int f = options().fsk;
     if (f == 0 || options().no_splitk || options().force_splitk > 1 || M <= 64 || f > 8) return 0;
     // (experiments: any grid in the ticket form, which never waits for a workgroup that is not running; the symmetric forms only when every workgroup is resident)
-    if (f > 1) return (K % (128 * f) == 0 && K / f >= 5 * 128 && (!options().fsk_symmetric || f * (((M + 255) / 256) * ((N + 255) / 256)) <= device_cus())) ? f : 0;
+    // (the ticket form deals the K-tiles unevenly where they do not divide — round 6; the symmetric forms keep equal slices)
+    if (f > 1) return (K % 128 == 0 && (K / 128) / f >= 5 && (!options().fsk_symmetric || (K % (128 * f) == 0 && f * (((M + 255) / 256) * ((N + 255) / 256)) <= device_cus()))) ? f : 0;
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     // residency guard: the slices of a tile hand over inside the kernel, one workgroup per CU (160 KiB of LDS): plan it only when the whole grid fits the CUs
     // this device reports (a CU-masked or partitioned device reports fewer) — otherwise the two-pass split-K or the single-pass tile runs
@@ -551,6 +553,16 @@ static int fsk_plan(int64_t M, int64_t N, int64_t K) {
     // tile on every such grid — 4096 x 1024 x 16384 68.8 against 62.8 us — at K = 28672 they win 2 - 6 %)
     if (t256 > cus / 8 && t256 <= cus / 4 && K >= 24576 && K % 512 == 0) return 4;
     return 0;
+}
+// ... and (round 6) by the TICKET form of the fused split-K of the 256 x 256 tile, where that is what the planner runs on the row-major operand (the Llama-70B `down` shard,
+// 4096 x 1024 x 28672: four slices over eight slabs, 99 us against 106 - 115 for the ring tile: profiles/r05_ab_down_shard_forms.txt): each slice's K range covers whole
+// slabs (or sits inside one) and the asm K-loop's activation cursor jumps at the slab boundaries (gemm_s8_sp256<..., KSL>).  Returns the slice count, 0 = not this way.
+static int kslabs_fsk_in_place(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t kps, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    if (options().no_kslabs || forced_variant() != V_AUTO || (slab_stride & 15) != 0 || slab_stride >= ((int64_t)1 << 40)) return 0;
+    const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
+    if (!(v == V_SP256_16 || v == V_SP128_16 || v == V_RING128)) return 0;        // (qlinear_core's `tiled`)
+    const int f = fsk_plan(M, N, K);
+    return (f > 1 && pq::fsk_kslabs_ok(K, kps, f)) ? f : 0;
 }
 
 size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -597,8 +609,8 @@ static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, cons
         if (workspace_bytes < need) return fail(PQ_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, need);
         if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(PQ_ERR_BAD_ALIGN, "%s: workspace must be 16-byte aligned", what);
         int32_t* slabs = static_cast<int32_t*>(workspace);
-        if (tm == 128) pq::launch_gemm_splitk_i32<128>(a, lda, b, ldb, slabs, M, N, K, ks, st);
-        else pq::launch_gemm_splitk_i32<256>(a, lda, b, ldb, slabs, M, N, K, ks, st);
+        if (tm == 128) pq::launch_gemm_splitk_i32<128>(a, lda, b, ldb, slabs, M, N, K, ks, st, epi.nxcd);
+        else pq::launch_gemm_splitk_i32<256>(a, lda, b, ldb, slabs, M, N, K, ks, st, epi.nxcd);
         switch (out_dtype) {
             case PQ_BF16: pq::launch_splitk_reduce<PQ_BF16>(slabs, ks, M, N, epi, st); break;
             case PQ_FP16: pq::launch_splitk_reduce<PQ_FP16>(slabs, ks, M, N, epi, st); break;
@@ -665,12 +677,37 @@ int32_t pq_qlinear_s8_t(const int8_t* a, int64_t lda, const float* a_scale, cons
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // ---- qlinear on STACKED activation codes (helpers above, before the C-ABI block)
+// (the short form knows neither the operand's base nor its strides: it returns what the layout pass needs — always enough, whichever way the call goes)
 size_t pq_qlinear_kslabs_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t k_per_slab) {
     CallScope scope_;
     if (M <= 0 || N <= 0 || K <= 0 || k_per_slab <= 0 || K % k_per_slab != 0) return 0;
     if (K == k_per_slab) return pq_qlinear_workspace_bytes(M, N, K);
-    if (kslabs_in_place(reinterpret_cast<const int8_t*>(16), k_per_slab, M * k_per_slab, k_per_slab, reinterpret_cast<const int8_t*>(16), K, M, N, K) != V_GENERIC) return 0;
     return align256((size_t)M * (size_t)K) + pq_qlinear_workspace_bytes(M, N, K);
+}
+// the exact form: decides on the operand the call will see (only the ALIGNMENT of `a` and `b` is looked at, nothing is read)
+size_t pq_qlinear_kslabs_workspace_bytes_for(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    CallScope scope_;
+    if (M <= 0 || N <= 0 || K <= 0 || k_per_slab <= 0 || K % k_per_slab != 0) return 0;
+    if (K == k_per_slab) return pq_qlinear_workspace_bytes(M, N, K);
+    if (const int f = kslabs_fsk_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K)) return pq::fsk_workspace_bytes(M, N, f);
+    if (kslabs_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K) != V_GENERIC) return 0;
+    return align256((size_t)M * (size_t)K) + pq_qlinear_workspace_bytes(M, N, K);
+}
+
+// which of the three ways (pq_hip.h) a pq_qlinear_s8_kslabs call with these operands and a workspace of `workspace_bytes` takes (dispatch audits, tests)
+const char* pq_kslabs_way_name(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const int8_t* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                               size_t workspace_bytes) {
+    CallScope scope_;
+    if (M <= 0 || N <= 0 || K <= 0 || k_per_slab <= 0 || K % k_per_slab != 0) return "invalid";
+    if (K == k_per_slab) return "one slab: pq_qlinear_s8";
+    if (const int f = kslabs_fsk_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K); f > 1 && workspace_bytes >= pq::fsk_workspace_bytes(M, N, f))
+        return f == 2 ? "in place: fused split-K x2" : f == 4 ? "in place: fused split-K x4" : f == 8 ? "in place: fused split-K x8" : "in place: fused split-K";
+    switch (kslabs_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K)) {
+        case V_RING128: return "in place: ring128";
+        case V_RING64X128: return "in place: ring64x128";
+        case V_RING64X64: return "in place: ring64x64";
+        default: return "layout pass";
+    }
 }
 
 int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, int64_t k_per_slab, const float* a_scale, const int8_t* b, int64_t ldb,
@@ -685,6 +722,23 @@ int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, 
     if (M == 0 || N == 0) return PQ_OK;
     if (K == k_per_slab) return pq_qlinear_s8(a, lda, a_scale, b, ldb, b_scale, bias, y, ldy, out_dtype, M, N, K, workspace, workspace_bytes, stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (const int f = kslabs_fsk_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K);
+        f > 1 && workspace != nullptr && workspace_bytes >= pq::fsk_workspace_bytes(M, N, f) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+        // (a workspace too small for the hand-over is not an error here: the ring tile below walks the slabs without one)
+        Range range_("pq:qlinear_s8_kslabs (K3+K4, fused split-K, slabs walked in place)");
+        pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy, 0};
+        epi.y_any_align = options().epi_any_align ? 1 : 0;
+        epi.nxcd = device_xcds();
+        if (!pq::epi_flags_valid(epi.flags, epi.bias != nullptr)) abort();
+        bool launched;
+        switch (out_dtype) {
+            case PQ_BF16: launched = pq::launch_gemm_fsk<PQ_BF16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st, slab_stride, k_per_slab); break;
+            case PQ_FP16: launched = pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st, slab_stride, k_per_slab); break;
+            default: launched = pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st, slab_stride, k_per_slab); break;
+        }
+        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8_kslabs: the split-K workspace could not be initialised (hipMemsetAsync failed)"); }
+        return check_launch("pq_qlinear_s8_kslabs");
+    }
     if (const Variant v = kslabs_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K); v != V_GENERIC) {
         Range range_("pq:qlinear_s8_kslabs (K3+K4, slabs walked in place)");
         pq::EpiArgs epi{a_scale, b_scale, bias, y, ldy, 0};

@@ -118,9 +118,9 @@ def qlinear_s8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.T
         if out.dim() != 2 or out.shape != (M, N) or (N > 1 and out.stride(1) != 1):
             raise ValueError(f"out must be a row-major [{M}, {N}] tensor, got {tuple(out.shape)} stride {out.stride()}")
     y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=xq.device)
-    wbytes = L.lib().pq_qlinear_workspace_bytes(M, N, K)        # > 0: split-K pays for this shape
-    wsp = _workspace(xq.device, wbytes) if wbytes else None
-    with torch.cuda.device(xq.device):
+    with torch.cuda.device(xq.device):          # (the planner's thresholds follow the CURRENT device's CU count: query and launch under the tensor's device)
+        wbytes = L.lib().pq_qlinear_workspace_bytes(M, N, K)        # > 0: split-K pays for this shape
+        wsp = _workspace(xq.device, wbytes) if wbytes else None
         L.check(L.lib().pq_qlinear_s8(xq.data_ptr(), L.ld(xq), xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), L.ld(y), code,
                                       M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes,
@@ -152,9 +152,9 @@ def qlinear_s8_t(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch
     if out is not None and (out.device != dev or out.dtype != out_dtype or out.shape != (N, M) or (M > 1 and out.stride(1) != 1)):
         raise ValueError(f"out must be a row-major [{N}, {M}] {out_dtype} tensor on {dev}")
     yt = out if out is not None else torch.empty((N, M), dtype=out_dtype, device=dev)
-    wbytes = L.lib().pq_qlinear_t_workspace_bytes(M, N, K)
-    wsp = _workspace(dev, wbytes) if wbytes else None
     with torch.cuda.device(dev):
+        wbytes = L.lib().pq_qlinear_t_workspace_bytes(M, N, K)
+        wsp = _workspace(dev, wbytes) if wbytes else None
         L.check(L.lib().pq_qlinear_s8_t(xq.data_ptr(), L.ld(xq), xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, yt.data_ptr(), L.ld(yt), code,
                                         M, N, K, wsp.data_ptr() if wsp is not None else None, wbytes, L.stream_ptr(xq)), "qlinear_s8_t")
@@ -165,7 +165,8 @@ def qlinear_s8_kslabs(xq_stacked: torch.Tensor, xs: torch.Tensor, wq: torch.Tens
                       out: torch.Tensor | None = None) -> torch.Tensor:
     """qlinear_s8 on STACKED activation codes xq_stacked[G, M, K/G] (contiguous: what an all-gather of the ranks' int8 column blocks leaves): slab s holds the
     columns [s*K/G, (s+1)*K/G) of the logical xq[M, K].  Same bits as qlinear_s8 on the row-major matrix (an integer sum has no order); the 128 x 128 ring tile
-    walks the slabs in place, every other shape takes one layout pass inside the call (C-ABI pq_qlinear_s8_kslabs)."""
+    walks the slabs in place, and so does the fused split-K of the 256 x 256 tile where the planner runs it (the Llama-70B `down` shard); every other shape takes one
+    layout pass inside the call (C-ABI pq_qlinear_s8_kslabs)."""
     L.require_gpu(xq_stacked, "qlinear_s8_kslabs(xq)")
     if xq_stacked.dim() != 3 or not xq_stacked.is_contiguous():
         raise ValueError("qlinear_s8_kslabs: activation codes must be a contiguous [G, M, K/G] int8 tensor")
@@ -186,9 +187,11 @@ def qlinear_s8_kslabs(xq_stacked: torch.Tensor, xs: torch.Tensor, wq: torch.Tens
     if out is not None and (out.device != dev or out.dtype != out_dtype or out.shape != (M, N) or (N > 1 and out.stride(1) != 1)):
         raise ValueError(f"out must be a row-major [{M}, {N}] {out_dtype} tensor on {dev}")
     y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=dev)
-    wbytes = L.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps)
-    wsp = _workspace(dev, wbytes) if wbytes else None
     with torch.cuda.device(dev):
+        # the exact query (it looks at the operands' alignment and strides): the fused split-K's hand-over slabs where the 256 x 256 tile walks the blocks in place,
+        # nothing where a ring tile does, the layout pass's M * K bytes otherwise
+        wbytes = L.lib().pq_qlinear_kslabs_workspace_bytes_for(xq_stacked.data_ptr(), kps, M * kps, kps, wq.data_ptr(), L.ld(wq), M, N, K)
+        wsp = _workspace(dev, wbytes) if wbytes else None
         L.check(L.lib().pq_qlinear_s8_kslabs(xq_stacked.data_ptr(), kps, M * kps, kps, xs.data_ptr(), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
                                              bias.data_ptr() if bias is not None else None, y.data_ptr(), L.ld(y), code, M, N, K,
                                              wsp.data_ptr() if wsp is not None else None, wbytes, L.stream_ptr(xq_stacked)), "qlinear_s8_kslabs")
@@ -218,9 +221,9 @@ def qlinear_dyn(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias=None) 
         xq = quantize(x2, axis=-1)
         return qlinear_s8(xq.int_data, xq.scale, wq, ws, bias, x.dtype).reshape(*x.shape[:-1], N)
     y = torch.empty((lead, N), dtype=x.dtype, device=x.device)
-    wbytes = L.lib().pq_qlinear_dyn_workspace_bytes(lead, N, K)
-    wsp = _workspace(x.device, max(wbytes, 256))
     with torch.cuda.device(x.device):
+        wbytes = L.lib().pq_qlinear_dyn_workspace_bytes(lead, N, K)
+        wsp = _workspace(x.device, max(wbytes, 256))
         L.check(L.lib().pq_qlinear_dyn(x2.data_ptr(), code, L.ld(x2), wq.data_ptr(), L.ld(wq), ws.data_ptr(),
                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), max(N, 1),
                                        lead, N, K, wsp.data_ptr(), wsp.numel(), L.stream_ptr(x)), "qlinear_dyn")
@@ -244,7 +247,8 @@ class _KPadded:
         # just freed — an address-based key would then match and the GEMM would run on the OLD padded weight
         import weakref
         wq = self.wq
-        key = (wq._version, wq.device, tuple(wq.shape))
+        # ... and ALSO on the address: `module.wq.data = other` / `wq.set_(...)` keep the Python object and do not bump its version
+        key = (wq._version, wq.device, tuple(wq.shape), wq.data_ptr(), wq.storage_offset())
         c = self.__dict__.get("_wq_pad")
         if c is None or c[0] != key or c[2]() is not wq:
             w = wq.new_zeros((wq.shape[0], kp))

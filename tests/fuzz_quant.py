@@ -100,6 +100,24 @@ def run(budget, seed):
       stk = torch.from_numpy(np.ascontiguousarray(a.reshape(M2, G2, K2 // G2).transpose(1, 0, 2))).cuda()
       got = pq.qlinear_s8_kslabs(stk, torch.from_numpy(xs2).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws2).cuda(), to_gpu(bv, code) if bv is not None else None, TD[code])
       bad += eqb(got, want, "epilogue[kslabs]", f"code={code} M={M2} N={N2} K={K2} G={G2} bias={bv is not None}")
+      # round 6: a FORCED fused split-K (f ticket slices of the 256 x 256 tile) on stacked blocks — slab counts 1 .. 8, slabs of 4 .. 9 K-tiles, slices that cover 1 / 2 / 4 slabs
+      # or a share of one: the asm K-loop's activation cursor jumps at the slab boundaries.  Against the int32 matmul + E1-E4 of the numpy oracle.
+      if n % 3 == 0:
+          f3 = int(rng.choice([2, 4, 8])); G3 = int(rng.choice([1, 2, 4, 8])); tps3 = int(rng.integers(4, 10))
+          while G3 * tps3 % f3 or G3 * tps3 // f3 < 5:
+              tps3 += 1
+          K3 = G3 * tps3 * 128
+          M3, N3 = int(rng.integers(65, 600)), int(rng.integers(129, 600))
+          a3 = rng.integers(-128, 128, (M3, K3), dtype=np.int8); b3 = rng.integers(-128, 128, (N3, K3), dtype=np.int8)
+          xs3 = rng.random(M3).astype(np.float32) + 1e-3; ws3 = rng.random(N3).astype(np.float32) * 0.02 + 1e-5
+          want3 = Q.epilogue(a3.astype(np.int32) @ b3.astype(np.int32).T, xs3, ws3, None, code)
+          stk3 = torch.from_numpy(np.ascontiguousarray(a3.reshape(M3, G3, K3 // G3).transpose(1, 0, 2))).cuda()
+          _pqlib.set_option("PQ_FSK", str(f3))
+          try:
+              got3 = pq.qlinear_s8_kslabs(stk3, torch.from_numpy(xs3).cuda(), torch.from_numpy(b3).cuda(), torch.from_numpy(ws3).cuda(), None, TD[code])
+          finally:
+              _pqlib.set_option("PQ_FSK", "")
+          bad += eqb(got3, want3, "epilogue[kslabs, forced fsk]", f"code={code} M={M3} N={N3} K={K3} G={G3} f={f3}")
       n += 1
   print(f"fuzz_quant: {n} problems in {time.time() - t0:.0f} s, mismatches: {bad}")
   return n, bad

@@ -112,13 +112,22 @@ def test_column_sharded_qlinear_on_a_column_sharded_input(pq, M, N, K, G, bias):
         assert torch.equal(y_r.view(torch.int16), y_ref[:, nb[r][0]:nb[r][1]].contiguous().view(torch.int16)), r
 
 
-@pytest.mark.parametrize("M,N,K,G,in_place", [(380, 484, 512, 4, True), (133, 633, 256, 2, True), (700, 300, 1024, 8, True), (2048, 1024, 2048, 8, True),      # slabs of ONE or two K-tiles (a fuzz find)
-                                             (4096, 1024, 28672, 8, True), (1024, 1024, 8192, 8, True), (2048, 512, 4096, 4, True), (700, 1000, 1024, 2, True),
-                                             (256, 4096, 2048, 2, True), (4096, 4096, 4096, 4, False), (2048, 4096, 11008, 2, False), (16, 1024, 8192, 8, False), (37, 50, 384, 3, False),
-                                             (300, 640, 960, 5, False)])
-def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
+def _way(L, stacked, wq, M, N, K, kps, nbytes=None, lda=None, stride=None):
+    lda = kps if lda is None else lda
+    stride = M * kps if stride is None else stride
+    need = L.pq_qlinear_kslabs_workspace_bytes_for(stacked.data_ptr(), lda, stride, kps, wq.data_ptr(), K, M, N, K)
+    return L.pq_kslabs_way_name(stacked.data_ptr(), lda, stride, kps, wq.data_ptr(), K, M, N, K, need if nbytes is None else nbytes).decode(), need
+
+
+@pytest.mark.parametrize("M,N,K,G,way", [(380, 484, 512, 4, "ring"), (133, 633, 256, 2, "ring"), (700, 300, 1024, 8, "ring"), (2048, 1024, 2048, 8, "ring"),      # slabs of ONE or two K-tiles (a fuzz find)
+                                        (4096, 1024, 28672, 8, "fused split-K x4"), (1024, 1024, 8192, 8, "ring"), (2048, 512, 4096, 4, "ring"), (700, 1000, 1024, 2, "ring"),
+                                        (256, 4096, 2048, 2, "ring"), (4096, 4096, 4096, 4, "layout"), (2048, 4096, 11008, 2, "fused split-K x2"), (2048, 4096, 11008, 4, "layout"), (16, 1024, 8192, 8, "layout"), (37, 50, 384, 3, "layout"),
+                                        (300, 640, 960, 5, "layout"), (2048, 4096, 11264, 2, "fused split-K x2"), (4096, 1024, 28672, 2, "fused split-K x4"), (4096, 1024, 28672, 4, "fused split-K x4")])
+def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, way):
     """pq_qlinear_s8_kslabs == pq_qlinear_s8 on the row-major codes, bit for bit: the ring tiles (128 x 128, 64 x 128, 64 x 64) walk the slabs in place (no
-    workspace); every other dispatch — 256-wide tiles (plain and fused split-K), the weight-streaming kernel, the generic kernel with K / G not a multiple of 128 — takes the layout pass.  All three output dtypes, with bias."""
+    workspace), the fused split-K of the 256 x 256 tile does where the planner runs it (round 6: the 70B `down` shard over 8, 4 and 2 slabs — two slabs per slice, one, half of one —
+    and a cfg-3-like `down`); every other dispatch — plain 256-wide tiles, the weight-streaming kernel, the generic kernel with K / G not a multiple of 128 — takes the layout pass.
+    All three output dtypes, with bias."""
     from protoquant_amd import _lib
     g = torch.Generator().manual_seed(M + N + K)
     xq = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).cuda()
@@ -127,7 +136,12 @@ def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
     ws = (torch.rand(N, generator=g) * 0.01 + 1e-4).cuda()
     kps = K // G
     stacked = xq.reshape(M, G, kps).permute(1, 0, 2).contiguous()
-    assert (_lib.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps) == 0) == in_place
+    L_ = _lib.lib()
+    name, need = _way(L_, stacked, wq, M, N, K, kps)
+    assert way in name, (name, need)
+    assert (need == 0) == (way == "ring") and L_.pq_qlinear_kslabs_workspace_bytes(M, N, K, kps) >= max(need, M * K)      # (the short query is always enough)
+    if "split-K" in way:        # without the hand-over workspace the ring tile (or the layout pass) still gives the answer: never an error
+        assert "split-K" not in _way(L_, stacked, wq, M, N, K, kps, nbytes=0)[0]
     for dt in (torch.bfloat16, torch.float16, torch.float32):
         bias = (torch.randn(N, generator=g) * 0.1).to(dt).cuda()
         for b in (None, bias):
@@ -139,10 +153,57 @@ def test_qlinear_on_stacked_code_blocks(pq, M, N, K, G, in_place):
         same(pq.qlinear_s8_kslabs(stacked, xs, wq, ws, None, torch.bfloat16), Q.epilogue(acc, xs.cpu().numpy(), ws.cpu().numpy(), None, 0), "vs oracle")
     try:                                        # the switch: the layout pass everywhere, same bits
         _lib.set_option("PQ_NO_KSLABS", "1")
-        assert _lib.lib().pq_qlinear_kslabs_workspace_bytes(M, N, K, kps) > 0
+        assert _way(L_, stacked, wq, M, N, K, kps)[0] == "layout pass"
         assert torch.equal(pq.qlinear_s8_kslabs(stacked, xs, wq, ws, None, torch.bfloat16).view(torch.int16), pq.qlinear_s8(xq, xs, wq, ws, None, torch.bfloat16).view(torch.int16))
     finally:
         _lib.set_option("PQ_NO_KSLABS", "")
+
+
+@pytest.mark.parametrize("M,N,K,G,f,pad_k,pad_m", [(300, 300, 4096, 2, 2, 0, 0), (300, 300, 4096, 4, 2, 16, 1), (130, 130, 4096, 8, 2, 0, 0), (260, 520, 4096, 2, 4, 0, 2), (513, 257, 8192, 8, 4, 128, 0),
+                                                   (700, 300, 8192, 8, 8, 0, 0), (256, 256, 5120, 1, 2, 0, 0), (300, 300, 6144, 4, 2, 0, 0), (2048, 1024, 28672, 8, 4, 0, 0),
+                                                   (300, 300, 3072, 8, 2, 0, 0), (300, 300, 6144, 3, 2, 0, 0), (300, 300, 7680, 4, 4, 0, 0)])
+def test_forced_fused_split_k_walks_stacked_blocks_in_place(pq, pq_opt, M, N, K, G, f, pad_k, pad_m):
+    """PQ_FSK=f forces f ticket slices wherever the shape admits them; on stacked blocks the asm K-loop's activation cursor jumps at the slab boundaries (kloop_p3_asm<5>):
+    slices of 1, 2 and 4 slabs (slabs of 4 K-tiles — the minimum — up to 28), slabs that hold 2 and 4 slices, one slab (= pq_qlinear_s8), padded rows and padded slabs.
+    Bit-identical to the contiguous form with the same forced split, to the unforced dispatch, and (small shapes) to the numpy oracle.  Shapes the in-place form does not
+    admit — slabs of 3 K-tiles, a slab count that neither divides nor is divided by the slice count, slices of fewer than 5 K-tiles — take another way, same bits."""
+    from protoquant_amd import _lib
+    L_ = _lib.lib()
+    g = torch.Generator().manual_seed(M + 7 * N + K + G)
+    xq = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).cuda()
+    xs, ws = (torch.rand(M, generator=g) * 0.01 + 1e-4).cuda(), (torch.rand(N, generator=g) * 0.01 + 1e-4).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    kps = K // G
+    want = pq.qlinear_s8(xq, xs, wq, ws, bias, torch.bfloat16)               # the unforced dispatch
+    pq_opt("PQ_FSK", str(f))
+    forced = pq.qlinear_s8(xq, xs, wq, ws, bias, torch.bfloat16)             # f slices on the row-major codes
+    buf = torch.full((G, M + pad_m, kps + pad_k), 77, dtype=torch.int8, device="cuda")
+    buf[:, :M, :kps] = xq.reshape(M, G, kps).permute(1, 0, 2)
+    lda, stride = kps + pad_k, (M + pad_m) * (kps + pad_k)
+    name, need = _way(L_, buf, wq, M, N, K, kps, lda=lda, stride=stride)
+    admits = G > 1 and kps % 128 == 0 and kps >= 512 and (G % f == 0 or f % G == 0) and K // f >= 640 and K % (128 * f) == 0 and M > 64 and M * N >= 128 * 128
+    assert (f"fused split-K x{f}" in name) == admits, (name, admits)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    wsp = torch.empty((need + 256,), dtype=torch.uint8, device="cuda")
+    for _ in range(2):          # (twice: the launcher zeroes its tickets itself)
+        y.zero_()
+        rc = L_.pq_qlinear_s8_kslabs(buf.data_ptr(), lda, stride, kps, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), y.data_ptr(), N, 0, M, N, K,
+                                     wsp.data_ptr() if need else None, need, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, L_.pq_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), want.view(torch.int16)) and torch.equal(forced.view(torch.int16), want.view(torch.int16))
+    if M * N * K <= 300 * 300 * 6144:
+        acc = Q.gemm_s8s8s32(xq.cpu().numpy(), wq.cpu().numpy())
+        same(y, Q.epilogue(acc, xs.cpu().numpy(), ws.cpu().numpy(), bias.cpu().view(torch.int16).numpy().view(np.uint16), 0), "vs oracle")
+    for dt in (torch.float16, torch.float32):                                # the other output types (module-level wrapper, contiguous blocks)
+        stacked = xq.reshape(M, G, kps).permute(1, 0, 2).contiguous()
+        got = pq.qlinear_s8_kslabs(stacked, xs, wq, ws, None, dt)
+        pq_opt("PQ_FSK", "")
+        ref = pq.qlinear_s8(xq, xs, wq, ws, None, dt)
+        pq_opt("PQ_FSK", str(f))
+        v = torch.int32 if dt == torch.float32 else torch.int16
+        assert torch.equal(got.view(v), ref.view(v)), dt
 
 
 @pytest.mark.parametrize("M,N,K,G,pad_k,pad_m", [(700, 300, 1024, 8, 16, 3), (4096, 1024, 8192, 8, 128, 0), (64, 96, 200, 2, 0, 0), (100, 130, 600, 3, 7, 2), (300, 4096, 2048, 2, 32, 1)])
@@ -163,7 +224,8 @@ def test_kslabs_with_padded_slabs_through_the_c_abi(pq, M, N, K, G, pad_k, pad_m
     lda, stride = kps + pad_k, (M + pad_m) * (kps + pad_k)
     # (the fast tiles need 16-byte aligned rows: an odd leading dimension or slab stride takes the layout pass, and the workspace query is told so through k_per_slab only —
     # a direct caller with unaligned slabs sizes the workspace for the layout pass itself)
-    need = max(L.pq_qlinear_kslabs_workspace_bytes(M, N, K, kps), ((M * K + 255) // 256) * 256 + L.pq_qlinear_workspace_bytes(M, N, K))
+    need = L.pq_qlinear_kslabs_workspace_bytes(M, N, K, kps)          # (the short query: always enough)
+    assert need >= ((M * K + 255) // 256) * 256 + L.pq_qlinear_workspace_bytes(M, N, K)
     wsp = torch.empty((need + 256,), dtype=torch.uint8, device="cuda")
     rc = L.pq_qlinear_s8_kslabs(buf.data_ptr(), lda, stride, kps, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, y.data_ptr(), N, 0, M, N, K,
                                 wsp.data_ptr(), need, torch.cuda.current_stream().cuda_stream)

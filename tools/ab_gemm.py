@@ -23,6 +23,13 @@ def load(path):
     L.pq_gemm_variant_name.restype = ctypes.c_char_p
     L.pq_gemm_variant_name.argtypes = [i64, i64, i64, i64, i64]
     L.pq_last_error.restype = ctypes.c_char_p
+    if hasattr(L, "pq_qlinear_kslabs_workspace_bytes_for"):
+        L.pq_qlinear_kslabs_workspace_bytes_for.restype = sz
+        L.pq_qlinear_kslabs_workspace_bytes_for.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, i64]
+        L.pq_kslabs_way_name.restype = ctypes.c_char_p
+        L.pq_kslabs_way_name.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, i64, sz]
+        L.pq_qlinear_s8_kslabs.restype = i32
+        L.pq_qlinear_s8_kslabs.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64, i64, vp, sz, vp]
     return L
 
 
@@ -42,8 +49,12 @@ def main():
         name, rest = spec.split("=", 1)
         path, _, opts = rest.partition("@")
         Lh = load(path)
+        Lh.stacked = 0
         for o in filter(None, opts.split(",")):
             k, v = o.split("=")
+            if k == "STACKED":          # pseudo-option: the activation codes as G stacked K-slabs through pq_qlinear_s8_kslabs (round 6)
+                Lh.stacked = int(v)
+                continue
             Lh.pq_set_option.restype = i32
             Lh.pq_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
             assert Lh.pq_set_option(k.encode(), v.encode()) == 0, (k, v)
@@ -64,12 +75,25 @@ def main():
         for name, L in libs:
             y = torch.zeros((M, N), dtype=dt[0], device=dev)
             wb = L.pq_qlinear_workspace_bytes(M, N, K)
+            Gs = getattr(L, "stacked", 0)
+            stk = None
+            if Gs:
+                kps = K // Gs
+                stk = xq.reshape(M, Gs, kps).permute(1, 0, 2).contiguous()
+                wb = L.pq_qlinear_kslabs_workspace_bytes_for(stk.data_ptr(), kps, M * kps, kps, wq.data_ptr(), K, M, N, K)
+                print(f"   [{name}: {L.pq_kslabs_way_name(stk.data_ptr(), kps, M * kps, kps, wq.data_ptr(), K, M, N, K, wb).decode()}, workspace {wb} B]", flush=True)
             wsp = torch.empty(max(wb, 16), dtype=torch.uint8, device=dev)
 
             cnt = [0]
 
-            def f(L=L, y=y, wsp=wsp, wb=wb, cnt=cnt):
+            def f(L=L, y=y, wsp=wsp, wb=wb, cnt=cnt, stk=stk, Gs=Gs):
                 wq = wrot[cnt[0] % len(wrot)]; cnt[0] += 1
+                if stk is not None:
+                    rc = L.pq_qlinear_s8_kslabs(stk.data_ptr(), K // Gs, M * (K // Gs), K // Gs, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(),
+                                                bias.data_ptr() if bias is not None else None, y.data_ptr(), N, dt[1], M, N, K,
+                                                wsp.data_ptr() if wb else None, wb, torch.cuda.current_stream().cuda_stream)
+                    assert rc == 0, L.pq_last_error()
+                    return
                 rc = L.pq_qlinear_s8(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(),
                                      bias.data_ptr() if bias is not None else None, y.data_ptr(), N, dt[1], M, N, K,
                                      wsp.data_ptr() if wb else None, wb, torch.cuda.current_stream().cuda_stream)

@@ -140,7 +140,7 @@ def acc(a, b, i, j):
 STEADY = [f"pa{it % 4}{it // 4}" for it in range(8)] + [f"qa{it % 2}{it // 2}" for it in range(4)]
 
 
-def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", tailprio=-1, snake=False):
+def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", tailprio=-1, snake=False, qslab=False):
     """One K-tile whose P data sits in P slot ps and Q data in Q slot qs.
     flavour: "full" (a tile kt+3 exists: both DMA sides), "q" (tile NT-3: the Q side of tile NT-1 and the scale vectors), "none"
     (tile NT-2: no DMA, every DMA piece must have landed at its barrier), "last" (tile NT-1: no next tile at all).
@@ -206,6 +206,20 @@ def gen_tile(E, ps, qs, dma_slots, t=0, ptr="bump", rstride=1, flavour="full", t
                         add(nxt, lambda h=h, jj=jj: E.dma_load(f"oq{h}{jj}", GQ + osfx))
                     if g == 3 and (ptr == "bump" or flavour == "q"):
                         add(nxt, lambda: E.add64(GQ, 128))
+                    if g == 3 and qslab and flavour == "full":
+                        # K-SLAB walk of the activation operand (stacked codes [G][M][K / G]: pq_qlinear_s8_kslabs): behind the Q pieces of every tile a
+                        # countdown of the K-tiles left in the current slab; on its borrow the cursor jumps by (slab stride - slab length) and the countdown
+                        # reloads.  Branch-free, six scalar instructions in one otherwise empty MFMA shadow; every later address of the turn is relative to the
+                        # cursor, so the jump may fall anywhere in it.
+                        def slab_step():
+                            E.salu("s_sub_u32 %[qcnt], %[qcnt], 1")
+                            E.salu("s_cselect_b32 %[qt0], %[qdl], 0")
+                            E.salu("s_cselect_b32 %[qt1], %[qdh], 0")
+                            E.salu("s_cselect_b32 %[qcnt], %[qrl], %[qcnt]")
+                            lo, hi = GQ[2:-1].split(":")
+                            E.salu(f"s_add_u32 s{lo}, s{lo}, %[qt0]")
+                            E.salu(f"s_addc_u32 s{hi}, s{hi}, %[qt1]")
+                        add(min(nxt + 1, 63), slab_step)
                     if g == 3 and flavour == "q":
                         # tile NT-3: the two scale vectors (1 KiB each: waves 0 and 1 of the workgroup, 4 floats per lane) follow the Q
                         # pieces into the P slot this tile has just vacated: no later DMA targets it, tile NT-2's vmcnt(0) covers them
@@ -274,9 +288,9 @@ DMA_PLANS = {
 #                    ptr: "bump" (s_add on the 64-bit K cursors per tile) | "imm" (immediate offsets, cursors advance once per turn),
 #                    rstride: fragment reads every rstride-th shadow, prio: s_setprio 1 on waves 4-7)
 def V(dma, dma_b=None, align8=True, nowait=False, nobar=False, ptr="imm", rstride=1, prio=0, tailprio=-1, nodma=False, nolds=False, nowalk=False, snake=False,
-      pinacc=False, rdrop=False, qdirect=False):
+      pinacc=False, rdrop=False, qdirect=False, qslab=False):
     return dict(dma=dma, dma_b=dma_b, align8=align8, nowait=nowait, nobar=nobar, ptr=ptr, rstride=rstride, prio=prio, tailprio=tailprio, nodma=nodma, nolds=nolds,
-                nowalk=nowalk, snake=snake, pinacc=pinacc, rdrop=rdrop, qdirect=qdirect)
+                nowalk=nowalk, snake=snake, pinacc=pinacc, rdrop=rdrop, qdirect=qdirect, qslab=qslab)
 
 
 VARIANTS = {
@@ -285,6 +299,7 @@ VARIANTS = {
     # (snake=True — boustrophedon MFMA order inside a quadrant, so that consecutive MFMAs always share one operand — measured +-0.2 %: profiles/r03_ab_asm_kloop.txt run 5)
     3: V("spread", nowait=True, nobar=True),       # timing only (wrong results): the same instruction stream without waits and barriers
     4: V("spread", pinacc=True),                   # the product loop with the accumulators PINNED where fsk_tail_asm wants them (gemm_s8_sp256<..., FSK>)
+    5: V("spread", pinacc=True, qslab=True),       # variant 4 whose activation cursor walks K-SLABS (stacked codes [G][M][K / G]; round 6): the fused split-K of pq_qlinear_s8_kslabs
     # (the placement sweep of profiles/r03_ab_asm_kloop.txt run 6 — q2dense / q3dense / alt4 / qearly / bursts above — put "spread", "alt4" and "qearly" within
     # 0.3 % of each other and the dense placements 2 - 4 % behind; the variants are not kept in the dev file)
     # timing only (wrong results), the ablations of round 2 on the asm loop: what the MFMA stream costs without its operand traffic
@@ -313,7 +328,7 @@ def gen_loop(E, tag, plan, cfg):
         if t:
             E.pad8()
             E.label(f"L_tile{t}_{tag}_%=")          # entry points of the phase jump (a statement may start anywhere in the turn)
-        gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"], snake=cfg["snake"])
+        gen_tile(E, kt % 3, kt % 2, DMA_PLANS[plan], t, cfg["ptr"], cfg["rstride"], snake=cfg["snake"], qslab=cfg["qslab"])
         assert E.fifo == STEADY, (E.fifo, STEADY)
         E.salu("s_sub_u32 %[cnt], %[cnt], 1")
         E.branch(f"s_cbranch_scc1 L_exit{t}_%=")
@@ -591,7 +606,7 @@ def gen_fsk_sym_tail(E, S):
     E.label(f"L_fsk{tag}_end_%=")
 
 
-def c_operands(pinacc=False):
+def c_operands(pinacc=False, qslab=False):
     outs, ins = [], []
     g = 0
     for a in range(2):
@@ -608,6 +623,8 @@ def c_operands(pinacc=False):
     outs.append('"+{s[88:89]}"(gp64)')
     outs.append('"+{s[90:91]}"(gq64)')
     outs.append('[cnt] "+s"(cnt)')
+    if qslab:
+        outs += ['[qcnt] "+s"(qs_cnt)', '[qt0] "=&s"(qs_t0)', '[qt1] "=&s"(qs_t1)']
     for ks in range(2):
         ins.append(f'[bp{ks}] "v"(bp[{ks}])')
         ins.append(f'[bph{ks}] "v"(bph[{ks}])')
@@ -617,6 +634,8 @@ def c_operands(pinacc=False):
             ins.append(f'[op{h}{jj}] "v"(offP[{h}][{jj}])')
             ins.append(f'[oq{h}{jj}] "v"(offQ[{h}][{jj}])')
     ins += ['[scsrc] "v"(scale_src)', '[sbw] "s"(sbw)', '[sbs] "s"(sbs)', '[dosc] "s"(do_scales)', '[phase] "s"(phase)', '[half] "s"(half)']
+    if qslab:
+        ins += ['[qdl] "s"(qs_dl)', '[qdh] "s"(qs_dh)', '[qrl] "s"(qs_reload)']
     return outs, ins
 
 
@@ -668,12 +687,13 @@ def render_fsk_tail():
     return out
 
 
-PRODUCT = (1, 4)               # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
+PRODUCT = (1, 4, 5)               # kloop_p3_asm.inc; every other variant goes to kloop_p3_asm_dev.inc (dev builds only: make ABLATION=1)
 OUT_DEV = os.path.join(ROOT, "protoquant_amd", "csrc", "kloop_p3_asm_dev.inc")
 ARGS = ("v4i (&acc)[2][2][4][2], v4i (&fPa)[4][2], v4i (&fPb)[4][2],\n"
         "        v4i (&fQa)[2][2], v4i (&fQb)[2][2], const uint32_t (&bp)[2], const uint32_t (&bph)[2], const uint32_t (&bq)[2],\n"
         "        const uint32_t (&offP)[2][2], const uint32_t (&offQ)[2][2], const int8_t*& gP, const int8_t*& gQ, uint32_t nfull,\n"
-        "        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales, uint32_t half")
+        "        uint32_t sbw, uint32_t phase, const void* scale_src, uint32_t sbs, uint32_t do_scales, uint32_t half,\n"
+        "        uint32_t qs_cnt = 0, uint32_t qs_dl = 0, uint32_t qs_dh = 0, uint32_t qs_reload = 0")
 CALL = "acc, fPa, fPb, fQa, fQb, bp, bph, bq, offP, offQ, gP, gQ, nfull, sbw, phase, scale_src, sbs, do_scales, half"
 
 
@@ -688,7 +708,7 @@ def render(vids, name, dev):
         out.append("// nfull tiles that issue both DMA sides in a loop over ring turns, then the three closing tiles.  phase: position of the first tile")
         out.append("// in the turn (0 behind the HIP code's tile 0; with immediate offsets the cursors come in moved back by phase * 128 bytes).")
         out.append("// scale_src / sbs / do_scales: the per-lane source address, the wave's LDS offset and the go-ahead of the epilogue's scale-vector")
-        out.append("// DMA, issued in the third tile from the end.")
+        out.append("// DMA, issued in the third tile from the end.  Variant 5: the activation cursor walks K-slabs (qs_*: see gen_tile's slab_step).")
     out.append("#pragma once")
     if not dev:
         out.append("#ifdef PQ_ABLATION_BUILD")
@@ -698,12 +718,15 @@ def render(vids, name, dev):
     out.append(f"template <int V> __device__ __forceinline__ void {name}(" + ARGS + ") {")
     out.append("    uint64_t gp64 = reinterpret_cast<uint64_t>(gP), gq64 = reinterpret_cast<uint64_t>(gQ);")
     out.append("    uint32_t cnt = nfull;")
+    if not dev:
+        out.append("    uint32_t qs_t0, qs_t1;      // (K-slab variant only: qs_cnt = K-tiles whose activation pieces are still to be issued from the current slab, minus one;")
+        out.append("    (void)qs_t0; (void)qs_t1; (void)qs_cnt; (void)qs_dl; (void)qs_dh; (void)qs_reload;      //  qs_dl / qs_dh = slab stride - slab length in bytes; qs_reload = K-tiles per slab - 1)")
     outs, ins = c_operands()
     first = True
     mixes = {}
     for vid in vids:
         E, per_tile = gen_variant(vid)
-        outs, ins = c_operands(VARIANTS[vid]["pinacc"])
+        outs, ins = c_operands(VARIANTS[vid]["pinacc"], VARIANTS[vid]["qslab"])
         mixes[vid] = per_tile
         out.append(f"    {'if' if first else 'else if'} constexpr (V == {vid}) {{")
         out.append(f"        // {VARIANTS[vid]}")
