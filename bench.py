@@ -12,22 +12,21 @@ blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides
 MEDIAN block (min / max alongside).  Per-kernel durations come from interleaved hipGraph replays of each kernel alone and of the
 compute step, and the script asserts GEMM + K1 <= 1.05 x step.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU — or by bench.py itself when no launcher set WORLD_SIZE: it then starts
-the same torch.distributed.run command as child processes before touching the GPU and relays rank 0's line): north_star's split — the weight is column-sharded
-over the ranks (N/G output channels each), the activation replicated, and ONE all-gather of the bf16 output shards per step rebuilds y[M, N]; the whole job is
-ONE M x N x K qlinear (strong scaling).  Every exchange form the repo holds is timed as a LEG by the same protocol (run_tp): torch.distributed's all-gather (rows /
-transposed shards) first, then libpq_rccl.so's plain gather + layout kernel, transposed shards (no layout pass) and 2 / 4 / 8 row blocks overlapped with the GEMM,
-each captured whole into the step's hipGraph and each under its own watchdog; over more than one rank every rank's work runs as a CHILD of a GPU-free supervisor
-process (supervise()) that prints the best verified line reported so far even if a native collective kills the worker.  Every leg is VERIFIED (each rank compares the y it holds, bit for bit, with the
-unsharded qlinear it computes itself); the headline `value` is the fastest verified leg, all legs are listed under `legs`.  The data-parallel figure (every rank its
-own batch, replicated weights, no collective) is reported under "dp"; `--mode dp` makes it the main line.
+This file holds the driver's command line, the N = 1 headline path and the dispatch; everything else lives in benchlib/ (round 6):
+  benchlib/tp.py         --gpus N > 1 (launched by torch.distributed.run, one process per GPU — or by bench.py itself when no launcher set WORLD_SIZE): north_star's split — the
+                         weight column-sharded over the ranks, the activation replicated, ONE all-gather of the bf16 output shards per step (strong scaling); every exchange form
+                         the repo holds is a timed, VERIFIED leg (torch.distributed rows / transposed first, then libpq_rccl.so's plain gather + layout kernel, transposed shards,
+                         2 / 4 / 8 overlapped row blocks, each captured whole into the step's hipGraph under its own watchdog); the headline `value` is the fastest verified leg;
+                         the data-parallel figure is the extra key "dp" (`--mode dp` makes it the main line)
+  benchlib/launch.py     the GPU-free per-rank supervisor (prints the best line reported so far even if a native collective kills the worker) and the self-launcher
+  benchlib/workloads.py  --workload mlp | llama8b | llama8b-linears | llama70b-shard: BASELINE configs[2], [3], [4]-per-rank as 1-GPU measurements
+  benchlib/cpu_baseline.py, context.py, common.py   the host-side baselines (the oracle module is handed in from HERE: the only import of oracle/ outside tests/ and smoke()),
+                         the stock torch-ROCm context legs, the shared plumbing
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (GEMM kernel vs the
-5.033 POPS dense int8 MFMA peak, timed live with HIP events), `cpu_baseline` (the QSPEC pipeline around torch._int_mm on the host
-cores, rank 0, after the timed regions, at every world size) and `verified`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (GEMM kernel vs the 5.033 POPS dense int8 MFMA peak, timed live with HIP events),
+`cpu_baseline` (the QSPEC pipeline around torch._int_mm on the host cores, rank 0, at every world size) and `verified`.
 """
 import argparse
-import json
 import os
 import sys
 import time
@@ -39,8 +38,19 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_INT8_TOPS = 5033.0     # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (MI355X_MICROARCH.md:28-34,435)
-PEAK_HBM_GBS = 8000.0       # spec; 6290 GB/s measured copy (MI355X_MICROARCH.md:36)
+from benchlib.common import PEAK_HBM_GBS, PEAK_INT8_TOPS, _claim_stdout, emit_json, graph_of, med, test_hooks, traffic_for  # noqa: E402
+from benchlib.launch import relay_launch, self_launch, supervise, supervisor_verdict  # noqa: E402,F401  (re-exported: tests/test_bench_supervisor.py)
+
+
+def oracle_module():
+    """oracle/torch_ref.py — imported HERE and nowhere else outside tests/ and smoke(): the cpu_baseline legs get the module handed in"""
+    from oracle import torch_ref
+    return torch_ref
+
+
+def cpu_baseline(M, N, K, budget_s=25.0):
+    from benchlib.cpu_baseline import cpu_baseline as f
+    return f(oracle_module(), M, N, K, budget_s=budget_s)
 
 
 def parse():
@@ -70,1263 +80,29 @@ def parse():
     ap.add_argument("--unfused-silu", action="store_true", help="mlp/llama8b workloads: torch silu*mul + K1 instead of the fused producer kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-supervisor", action="store_true", help="tp over > 1 rank without the per-rank supervisor process (the worker prints its own line)")
     ap.add_argument("--native-timeout", type=float, default=120.0,
                     help="tp over RCCL: seconds EACH leg that drives the native exchange (libpq_rccl.so) may take; when one does not finish, the fastest verified leg "
                          "among those that did (the torch.distributed legs run first) is printed with \"native_exchange\": \"hung\" (a multi-GPU run is never lost to a hung collective)")
-    ap.add_argument("--simulate-native-hang", action="store_true", help="tests: the native path never returns (the watchdog must print the safe line)")
-    ap.add_argument("--supervise", action="store_true", help="tests: run the tp worker under its supervisor process also at 1 rank (always on at > 1 rank)")
-    ap.add_argument("--no-supervisor", action="store_true", help="tp over > 1 rank without the per-rank supervisor process (the worker prints its own line)")
-    ap.add_argument("--simulate-native-crash", action="store_true", help="tests: the worker kills itself (SIGSEGV) when it reaches the native exchange")
-    ap.add_argument("--simulate-leg-hang", default="", help="tests: the named native leg never returns (the watchdog must print the best of the legs that finished before it)")
     return ap.parse_args()
-
-
-def graph_of(fn, n, dev=None):
-    """A hipGraph holding n consecutive calls of fn (launched on torch's current stream at replay)."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        fn()
-    torch.cuda.current_stream().wait_stream(s)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(n):
-            fn()
-    return g
-
-
-def host_cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def cpu_baseline(M, N, K, budget_s=25.0):
-    """'protoquant's own CPU path': QSPEC around torch._int_mm on this box's host cores (oracle/torch_ref.py), the same
-    M x N x K bf16 qlinear as the GPU step.  Thread sweep {1, 8, 16, 32, cores this process may run on}: torch's default
-    (every core of the machine) oversubscribes whatever the container is granted and ran SLOWER than one thread in round 1,
-    so the stated baseline is the best of the sweep, with per-stage times (min and median) at that setting."""
-    from oracle import torch_ref as R
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
-    wq, ws = R.quantize_ref(w, 1)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sweep = sorted({t for t in (1, 8, 16, 32, avail) if t <= avail})
-    default_threads = torch.get_num_threads()
-    ops = 2.0 * M * N * K
-    t_start = time.perf_counter()
-    rows = {}
-
-    def stages():
-        t0 = time.perf_counter(); xq, xs = R.quantize_ref(x, 1)
-        t1 = time.perf_counter(); acc = R.int_gemm_ref(xq, wq)
-        t2 = time.perf_counter(); R.epilogue_ref(acc, xs, ws, None, x.dtype)
-        t3 = time.perf_counter()
-        return (t1 - t0, t2 - t1, t3 - t2, t3 - t0)
-    try:
-        for nt in sweep:
-            torch.set_num_threads(nt)
-            stages()                                   # warm-up (thread pool, oneDNN primitive cache)
-            reps = []
-            while len(reps) < 5 and (len(reps) < 2 or time.perf_counter() - t_start < budget_s * (sweep.index(nt) + 1) / len(sweep)):
-                reps.append(stages())
-            tot = sorted(r[3] for r in reps)
-            rows[nt] = {"reps": len(reps), "ms_median": round(tot[len(tot) // 2] * 1e3, 2), "ms_min": round(tot[0] * 1e3, 2),
-                        "stage_ms_min": {"quantize": round(min(r[0] for r in reps) * 1e3, 2), "int_mm": round(min(r[1] for r in reps) * 1e3, 2),
-                                         "epilogue": round(min(r[2] for r in reps) * 1e3, 2)},
-                        "stage_ms_median": {"quantize": round(sorted(r[0] for r in reps)[len(reps) // 2] * 1e3, 2),
-                                            "int_mm": round(sorted(r[1] for r in reps)[len(reps) // 2] * 1e3, 2),
-                                            "epilogue": round(sorted(r[2] for r in reps)[len(reps) // 2] * 1e3, 2)},
-                        "tops_median": round(ops / tot[len(tot) // 2] / 1e12, 4)}
-    finally:
-        torch.set_num_threads(default_threads)
-    best = min(rows, key=lambda t: rows[t]["ms_median"])
-    return {"value": rows[best]["tops_median"], "unit": "TOPS", "cores": best, "kind": "port",
-            "sample": f"{rows[best]['reps']} reps of the full {M}x{N}x{K} bf16 qlinear (quantize + torch._int_mm + epilogue) per thread count, median; best of the sweep",
-            "ms_per_step": rows[best]["ms_median"], "ms_per_step_min": rows[best]["ms_min"],
-            "stage_ms_min": rows[best]["stage_ms_min"], "stage_ms_median": rows[best]["stage_ms_median"],
-            "primitive": "torch._int_mm (oneDNN s8s8s32) + torch float ops", "host_cpu": host_cpu_model(),
-            "cores_available": avail, "torch_default_threads": default_threads,
-            "thread_sweep_tops_median": {str(t): rows[t]["tops_median"] for t in rows},
-            "thread_sweep_ms_median": {str(t): rows[t]["ms_median"] for t in rows},
-            "value_1_thread": rows[1]["tops_median"] if 1 in rows else None}
-
-
-def gpu_context(x, wq, ws, y_ref, med_of):
-    """Context, not the contract's baseline: the SAME qlinear written with stock torch-ROCm ops around `torch._int_mm` on THIS GPU — what
-    the reference's Python would execute on an MI355X (hipBLASLt int8 GEMM with int32 output, eager elementwise kernels around it) —
-    plus the int8 GEMM alone and the un-quantised bf16 linear.  hipGraph replays (no host gaps), HIP events, median.  The eager pipeline's
-    result is compared with the library's y (QSPEC written in torch ops; see the note on torch-ROCm's division below)."""
-    wt = wq.t()
-
-    def pipeline():
-        xf = x.float()
-        amax = xf.abs().amax(dim=1, keepdim=True)
-        s = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax))
-        xq = torch.round(xf / s).clamp_(-127, 127).to(torch.int8)
-        acc = torch._int_mm(xq, wt)
-        return ((acc.float() * s) * ws).to(torch.bfloat16)
-    out = {}
-    try:
-        yp = pipeline()
-        # torch-ROCm's elementwise float division on the GPU is not the correctly rounded one (a few per cent of the row scales differ in
-        # the last bit from the CPU's and from this library's, which matches the CPU bit for bit), so a small share of outputs differs
-        out["outputs_differing_from_library"] = int((yp.view(torch.int16) != y_ref.view(torch.int16)).sum().item())
-        out["outputs"] = int(yp.numel())
-        out["max_abs_diff"] = float((yp.float() - y_ref.float()).abs().max().item())
-        w_bf16 = (wq.float() * ws[:, None]).to(torch.bfloat16)
-        xq0 = torch.round(x.float()).clamp_(-127, 127).to(torch.int8)
-        legs = {"torch_rocm_int8_pipeline_us": pipeline, "torch_int_mm_alone_us": lambda: torch._int_mm(xq0, wt),
-                "torch_bf16_linear_us": lambda: torch.nn.functional.linear(x, w_bf16)}
-        n = 5
-        graphs = {k: graph_of(f, n) for k, f in legs.items()}
-        for g in graphs.values():
-            g.replay()
-        torch.cuda.synchronize()
-        ts = {k: [] for k in legs}
-        for _ in range(9):
-            for k, g in graphs.items():
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); g.replay(); b.record(); b.synchronize()
-                ts[k].append(a.elapsed_time(b) * 1e3 / n)
-        for k, v in ts.items():
-            out[k] = round(med_of(v), 2)
-        out["what"] = ("stock torch-ROCm ops on this GPU, hipGraph replays: the QSPEC pipeline around torch._int_mm (hipBLASLt int8, int32 out) = what the "
-                       "reference's Python would run here; that GEMM alone; the bf16 linear the int8 path replaces")
-    except Exception as e:      # context must never lose the main line
-        out["error"] = str(e)[:300]
-    return out
-
-
-def run_mlp(args):
-    """BASELINE configs[2]: gate/up (horizontally fused, N = 2 x 11008) and down as qlinear at M = 2048; silu(g)*u is
-    fused into the quantisation of down's input (pq_silu_mul_quant_rowwise; --unfused-silu restores the stock torch-ROCm
-    elementwise + K1 pair).  One step = the whole block; 554.05 GOP of int8 GEMM."""
-    import protoquant_amd as pq
-    M, H, I = 2048, 4096, 11008
-    dev = torch.device("cuda", 0)
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(M, H, generator=g).to(torch.bfloat16).to(dev)
-    mk = lambda o, i: pq.qlinear.from_linear(torch.nn.Linear(i, o, bias=False, dtype=torch.bfloat16).to(dev))
-    gate_up = pq.FusedQLinear([mk(I, H), mk(I, H)])
-    down = mk(H, I)
-
-    if args.unfused_silu:
-        def block():
-            gt, up = gate_up(x)
-            return down(torch.nn.functional.silu(gt) * up)
-    else:
-        mlp = pq.GatedMLP(gate_up, down)       # silu*mul fused into the quantisation of down's input (one pass, no bf16 h)
-
-        def block():
-            return mlp(x)
-
-    for _ in range(args.warmup):
-        block()
-    torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
-        try:
-            s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                block()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                block()
-        except Exception as e:
-            print(f"[bench] hipGraph capture failed ({e}); running eager", file=sys.stderr)
-            graph = None
-    run = (lambda: graph.replay()) if graph is not None else block
-    for _ in range(20):
-        run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ops = 2.0 * M * (2 * I) * H + 2.0 * M * H * I
-    # The replayed block keeps its 135 MB of int8 weights in the 256-MB Infinity Cache; a layer inside a model reads its weights once per
-    # pass, from HBM.  Extra key: the same block over 6 layers' worth of distinct weights (810 MB), one layer after the other.
-    hbm_fed = None
-    if not args.unfused_silu and not args.no_graph:
-        try:
-            layers = [mlp] + [pq.GatedMLP(pq.FusedQLinear([mk(I, H), mk(I, H)]), mk(H, I)) for _ in range(5)]
-
-            def stack():
-                for l_ in layers:
-                    l_(x)
-            stack(); torch.cuda.synchronize()
-            s2 = torch.cuda.Stream(); s2.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s2):
-                stack()
-            torch.cuda.current_stream().wait_stream(s2)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                stack()
-            for _ in range(5):
-                g2.replay()
-            torch.cuda.synchronize()
-            n2 = max(5, args.steps // 6)
-            t1 = time.perf_counter()
-            for _ in range(n2):
-                g2.replay()
-            torch.cuda.synchronize()
-            d2 = (time.perf_counter() - t1) / (n2 * len(layers))
-            hbm_fed = {"ms_per_block": round(d2 * 1e3, 5), "value": round(ops / d2 / 1e12, 2), "unit": "TOPS",
-                       "what": f"{len(layers)} blocks with distinct weights ({len(layers) * 135} MB) run one after the other: every block streams its weights from HBM"}
-        except Exception as e:      # an extra figure must never lose the main line
-            print(f"[bench] HBM-fed leg failed: {e}", file=sys.stderr)
-    emit_json({"metric": "int8 TOPS, Llama MLP block (gate/up/down as qlinear)", "value": round(ops * args.steps / dt / 1e12, 2),
-                      "unit": "TOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                      "config": {"workload": "Llama MLP block 4096->11008->4096, seq 2048, gate+up fused (BASELINE configs[2])",
-                                 "silu_mul": "torch elementwise + K1" if args.unfused_silu else "fused into K1 (pq_silu_mul_quant_rowwise)",
-                                 "launch": "hipgraph" if graph is not None else "eager",
-                                 "weights": "the one block replayed: its 135 MB of int8 weights stay in the Infinity Cache (see weights_from_hbm)"},
-                      "weights_from_hbm": hbm_fed,
-                      "roofline": {"bound": "mfma", "achieved": round(ops * args.steps / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                                   "frac": round(ops * args.steps / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "whole block incl. both activation quantisations (the second fused with silu*mul), not a single kernel"},
-                      "cpu_baseline": None})
-
-
-def run_llama8b_linears(args):
-    """BASELINE configs[3], linears only: 32 layers x {fused qkv 4096->6144, o 4096->4096, fused gate+up 4096->28672,
-    down 14336->4096} + lm_head 4096->128256 at M = 4096 tokens (bs 1, seq 4096): 61.48 TOP of int8 GEMM per pass.
-    Synthetic int8 weights (gaussian codes) and scales; every activation quantisation (K1) is included; attention,
-    norms and rope are NOT run (the o-projection input is a slice of the qkv output, the down input is silu(g)*u)."""
-    import protoquant_amd as pq
-    from protoquant_amd.qtensor import QTensor
-    dev = torch.device("cuda", 0)
-    M, H, I, V, L = args.tokens, 4096, 14336, 128256, 32
-
-    def mkq(n, k):
-        wq = (torch.randn(n, k, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
-        return pq.qlinear.from_qtensor(QTensor(wq, torch.rand(n, device=dev) * 1e-3 + 1e-4, 1, torch.bfloat16, wq.shape))
-
-    layers = [(mkq(6144, H), mkq(H, H), mkq(2 * I, H), mkq(H, I)) for _ in range(L)]
-    head = mkq(V, H)
-    x0 = torch.randn(M, H, device=dev).to(torch.bfloat16)
-
-    norm_w = torch.ones(H, device=dev, dtype=torch.bfloat16)
-
-    def fwd():
-        x = x0
-        for qkv, o, gu, down in layers:
-            # --norms: the layer's two RMSNorms, fused into the quantisation of the qkv and gate/up inputs (K1n replaces K1)
-            a = qkv(pq.rmsnorm_quantize(x, norm_w, 1e-5) if args.norms else x)[:, :H]      # a strided view: K1 takes the leading dimension
-            x = o(a)
-            g_u = gu(pq.rmsnorm_quantize(x, norm_w, 1e-5) if args.norms else x)
-            if args.unfused_silu:
-                x = down(torch.nn.functional.silu(g_u[:, :I]) * g_u[:, I:])
-            else:
-                x = down(pq.silu_mul_quantize(g_u[:, :I], g_u[:, I:]))
-        return head(x)
-
-    for _ in range(2):
-        fwd()
-    torch.cuda.synchronize()
-    run, launch = fwd, "eager"
-    if M <= 512 and not args.no_graph:        # decode-sized passes are launch-bound from Python: replay them from a hipGraph
-        s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s_):
-            fwd()
-        torch.cuda.current_stream().wait_stream(s_)
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            fwd()
-        run, launch = gr.replay, "hipgraph"
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    ops = L * (2.0 * M * 6144 * H + 2.0 * M * H * H + 2.0 * M * 2 * I * H + 2.0 * M * H * I) + 2.0 * M * V * H
-    wbytes = L * (6144 * H + H * H + 2 * I * H + H * I) + V * H          # int8 weight bytes streamed per pass
-    if M <= 512:       # decode-like: the pass is a streaming read of the weights — report it against HBM, not MFMA
-        emit_json({"metric": f"weight-streaming TB/s, Llama-3-8B linears at {M} tokens (decode-like)", "value": round(wbytes / dt / 1e12, 3),
-                          "unit": "TB/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                          "config": {"workload": f"Llama-3-8B every linear as qlinear (qkv and gate/up fused) at {M} tokens, linears + quant passes only",
-                                     "rmsnorm": "fused into K1 (pq_rmsnorm_quant_rowwise)" if args.norms else "not run", "launch": launch,
-                                     "weight_bytes_per_step": wbytes, "int8_tops": round(ops / dt / 1e12, 2)},
-                          "roofline": {"bound": "hbm", "achieved": round(wbytes / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(wbytes / dt / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                                       "note": "whole pass (290 kernels); algorithmic bytes = the int8 weights only"},
-                          "cpu_baseline": None})
-        return
-    emit_json({"metric": "int8 TOPS, Llama-3-8B linears at prefill seq 4096", "value": round(ops / dt / 1e12, 2), "unit": "TOPS",
-                      "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                      "config": {"workload": "Llama-3-8B every linear as qlinear (qkv and gate/up fused), bs 1 seq 4096, linears + quant passes only (BASELINE configs[3])",
-                                 "rmsnorm": "fused into K1 (pq_rmsnorm_quant_rowwise)" if args.norms else "not run",
-                                 "launch": launch, "int8_ops_per_step": ops},
-                      "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                                   "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "whole pass incl. every activation quantisation (silu*mul fused into down's) and the strided read of the qkv slice"},
-                      "cpu_baseline": None})
-
-
-def run_llama8b(args):
-    """BASELINE configs[3] as a MODEL: transformers' LlamaForCausalLM at Llama-3-8B dims (hidden 4096, intermediate 14336, 32
-    layers, 32 heads / 8 KV heads, vocab 128256) with synthetic weights initialised on the GPU, every nn.Linear swapped to qlinear
-    (swap_linears: the product path quantises the bf16 weights), gated MLPs as GatedMLP, both RMSNorms of every layer fused into
-    the activation quantisation and q/k/v as one fused GEMM (protoquant_amd.llama.fuse_llama_layers).  Prefill, bs 1, seq 4096.
-    Reported: end-to-end latency; the time of the int8 linear path (every quantisation + GEMM launch, measured with HIP events
-    around those modules) and its TOPS over the 61.48 TOP of linear work; attention / rope / residual / embedding / final norm
-    (stock torch-ROCm ops) as the remainder."""
-    import transformers as tr
-    import protoquant_amd as pq
-    from protoquant_amd.llama import RMSNormQuant, fuse_llama_layers
-    dev = torch.device("cuda", 0)
-    S = args.tokens
-    cfg = tr.LlamaConfig(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
-                         num_key_value_heads=8, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0, attn_implementation="sdpa")
-    t0 = time.perf_counter()
-    torch.manual_seed(1234)
-    with torch.device(dev):
-        prev = torch.get_default_dtype()
-        torch.set_default_dtype(torch.bfloat16)
-        try:
-            model = tr.LlamaForCausalLM(cfg).eval()
-        finally:
-            torch.set_default_dtype(prev)
-    pq.swap_linears(model, fuse_gated_mlp=True)
-    nfused = 0 if args.no_layer_fusion else fuse_llama_layers(model)
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t0
-    ids = torch.randint(0, cfg.vocab_size, (1, S), device=dev)
-
-    # HIP events around every int8-path module (fused norm+quant, qlinear / FusedQLinear / GatedMLP); attention's projections
-    # sit inside self_attn, so the hooks go on the leaves
-    from protoquant_amd.llama import _FusedSlice, _SharedFused
-    inside = set()                       # qlinears that a timed parent already covers
-    for m in model.modules():
-        if isinstance(m, (pq.GatedMLP, _SharedFused)):
-            inside.update(id(sub) for sub in m.modules() if sub is not m)
-    timed = [m for m in model.modules()
-             if isinstance(m, (RMSNormQuant, pq.GatedMLP)) or (isinstance(m, _FusedSlice) and m.index == 0)
-             or (isinstance(m, (pq.qlinear, pq.FusedQLinear)) and id(m) not in inside)]
-    spans, timing = [], {"on": False}
-
-    def pre(mod, inp):
-        if timing["on"]:
-            mod._span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            mod._span[0].record()
-
-    def post(mod, inp, out):
-        if timing["on"]:
-            mod._span[1].record()
-            spans.append(mod._span)
-    for m in timed:
-        m.register_forward_pre_hook(pre); m.register_forward_hook(post)
-
-    def fwd():
-        with torch.no_grad():
-            return model(ids, use_cache=False, logits_to_keep=0).logits
-    for _ in range(max(1, args.warmup if args.warmup < 5 else 2)):
-        out = fwd()
-    torch.cuda.synchronize()
-    assert out.shape == (1, S, cfg.vocab_size)
-    lat = []
-    for _ in range(max(3, min(args.steps, 10))):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter(); fwd(); torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t0)
-    lat.sort()
-    e2e = lat[len(lat) // 2]
-    timing["on"] = True
-    lin_t = []
-    for _ in range(3):
-        spans.clear()
-        fwd(); torch.cuda.synchronize()
-        lin_t.append(sum(a.elapsed_time(b) for a, b in spans) * 1e-3)
-    timing["on"] = False
-    lin_t.sort()
-    t_lin = lin_t[len(lin_t) // 2]
-    L, H, I, V = cfg.num_hidden_layers, 4096, 14336, cfg.vocab_size
-    ops = L * (2.0 * S * 6144 * H + 2.0 * S * H * H + 2.0 * S * 2 * I * H + 2.0 * S * H * I) + 2.0 * S * V * H
-    emit_json({"metric": "int8 TOPS of the linear path + end-to-end prefill latency, Llama-3-8B (every nn.Linear as qlinear), bs 1 seq 4096",
-                      "value": round(ops / t_lin / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(lat), "warmup": 2, "ms_per_step": round(e2e * 1e3, 3),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                      "config": {"workload": f"transformers LlamaForCausalLM at Llama-3-8B dims ({L} layers), synthetic weights, swap_linears(fuse_gated_mlp) + fuse_llama_layers, prefill bs 1 seq {S} (BASELINE configs[3])",
-                                 "layers_fused": nfused, "attention": "stock torch-ROCm (sdpa), rope / residual / embedding / final norm stock",
-                                 "int8_ops_per_step": ops, "build_seconds": round(t_build, 1)},
-                      "end_to_end_ms": round(e2e * 1e3, 3), "end_to_end_ms_min": round(lat[0] * 1e3, 3),
-                      "linear_path_ms": round(t_lin * 1e3, 3), "other_ops_ms": round((e2e - t_lin) * 1e3, 3),
-                      "roofline": {"bound": "mfma", "achieved": round(ops / t_lin / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                                   "frac": round(ops / t_lin / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "all int8-path launches of the forward: fused RMSNorm+quant (x2 per layer), fused qkv, o, fused gate+up, silu*mul+quant, down, lm_head (its own K1); HIP events around those modules"},
-                      "cpu_baseline": None})
-
-
-def run_llama70b_shard(args):
-    """BASELINE configs[4], ONE rank's compute at the real shapes: Llama-3-70B (hidden 8192, intermediate 28672, 80 layers, 64 heads /
-    8 KV heads, vocab 128256) with every linear's int8 weight column-sharded over G = 8 GPUs, M = 4096 tokens (seq is not stated in
-    BASELINE.json: assumed 4096 as in configs[3]).  This process plays rank 0 on one GPU: per layer the fused q/k/v shard
-    (N = 10240 / 8 = 1280), the o shard (1024), the fused gate+up shard (2 x 3584) and the down shard (1024, K = 28672), each with
-    its activation quantisation on the replicated input (RMSNorm fused for q/k/v and gate/up; silu*mul needs the GATHERED gate/up in this
-    configuration, so down's input is quantised by plain K1), plus the lm_head shard (16032).  No collective runs (one GPU): the
-    exchange is priced from the bytes with the xGMI link model of DESIGN.md section 6, and stated as modelled."""
-    import protoquant_amd as pq
-    from protoquant_amd import _lib as L_
-    from protoquant_amd.qtensor import QTensor
-    dev = torch.device("cuda", 0)
-    G, M, H, I, V, L = 8, args.tokens, 8192, 28672, 128256, args.layers if args.layers != 32 else 80
-    KVD = 1024
-
-    def mkq(n, k):
-        wq = (torch.randn(n, k, device=dev) * 28).round().clamp(-127, 127).to(torch.int8)
-        return pq.qlinear.from_qtensor(QTensor(wq, torch.rand(n, device=dev) * 1e-3 + 1e-4, 1, torch.bfloat16, wq.shape))
-    n_qkv, n_o, n_gu, n_down, n_head = (H + 2 * KVD) // G, H // G, 2 * I // G, H // G, V // G
-    # NL distinct layers' weights take turns (105 MB of shards per layer: two sets would sit in the 256-MB Infinity Cache; eight — 840 MB — make every layer stream its
-    # weights from HBM, as the 80 distinct layers of the model do)
-    NL = 8
-    layers = [(mkq(n_qkv, H), mkq(n_o, H), mkq(n_gu, H), mkq(n_down, I)) for _ in range(NL)]
-    head = mkq(n_head, H)
-    x_h = torch.randn(M, H, device=dev).to(torch.bfloat16)          # stands for a gathered hidden state
-    x_i = torch.randn(M, I, device=dev).to(torch.bfloat16)          # stands for the gathered silu(g) * u
-    norm_w = torch.ones(H, device=dev, dtype=torch.bfloat16)
-
-    def fwd():
-        for l in range(L):
-            qkv, o, gu, down = layers[l % NL]
-            qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-            o(x_h)
-            gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-            down(x_i)
-        return head(x_h)
-    for _ in range(2):
-        fwd()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(max(3, min(args.steps, 10))):
-        t0 = time.perf_counter(); fwd(); torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    dt = ts[len(ts) // 2]
-    ops = L * 2.0 * M * (n_qkv * H + n_o * H + n_gu * H + n_down * I) + 2.0 * M * n_head * H
-    # Extra key — the ROW-SHARDED PAIRING of SURVEY section 8(f)4 (RowShardedQLinear / ShardedGatedMLP): o and down take the LOCAL shard of
-    # their producer's output (this rank's heads / intermediate channels) against the matching K-slice of the weight and emit f32 partials
-    # [M, H] for a reduce-scatter; no gather sits between gate/up and down, and silu*mul is fused into the local quantisation.  Same int8 ops
-    # per rank, GEMM shapes 4096 x 8192 x 1024 and 4096 x 8192 x 3584 instead of the 1024-wide column shards.
-    pairing = None
-    try:
-        rl = [(mkq(H, H // G), mkq(H, I // G)) for _ in range(NL)]
-        x_a = torch.randn(M, H // G, device=dev).to(torch.bfloat16)          # stands for this rank's heads of the attention output
-
-        def fwd_row():
-            for l in range(L):
-                qkv, _o, gu, _d = layers[l % NL]
-                o_r, d_r = rl[l % NL]
-                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-                xa = pq.quantize(x_a)
-                pq.qlinear_s8(xa.int_data, xa.scale, o_r.wq, o_r.ws, None, torch.float32)
-                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(I // G, dim=-1)
-                hq = pq.silu_mul_quantize(g_, u_)
-                pq.qlinear_s8(hq.int_data, hq.scale, d_r.wq, d_r.ws, None, torch.float32)
-            return head(x_h)
-        fwd_row(); torch.cuda.synchronize()
-        tr = []
-        for _ in range(3):
-            t0 = time.perf_counter(); fwd_row(); torch.cuda.synchronize()
-            tr.append(time.perf_counter() - t0)
-        dr = sorted(tr)[1]
-        # per layer two exchanges: reduce-scatter of the f32 partials [M, H] + all-gather of the bf16 row blocks (the next column-sharded
-        # linear wants the activation replicated): a rank moves 7/8 of M*H*4 + 7/8 of M*H*2 bytes each time
-        moved = L * 2 * (G - 1) / G * (M * H * 4 + M * H * 2) + 2.0 * M * V * (G - 1) / G
-        pairing = {"ms_per_step": round(dr * 1e3, 3), "value": round(ops / dr / 1e12, 2), "unit": "TOPS",
-                   "gemm_shapes": f"4096x{n_qkv}x8192 (fused qkv, column), 4096x8192x{H // G} (o, row), 4096x{n_gu}x8192 (fused gate+up, column), 4096x8192x{I // G} (down, row)",
-                   "modelled_exchange_ms": round(moved / (7 * 153e9) * 1e3, 2),
-                   "model": "per layer 2 x (reduce-scatter of f32 partials [M,H] + all-gather of bf16 row blocks), 7 xGMI links x 153 GB/s; NOT measured"}
-        del rl
-    except Exception as e:      # an extra figure must never lose the main line
-        print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
-    # Extra key — the INT8-CODE EXCHANGE between gate/up and down (ColumnShardedGatedMLP: everything stays column-sharded, as north_star asks): the rank computes
-    # silu*mul on ITS 3584 intermediate channels only — row amax of the local block, [all-reduce(max) of 4096 32-bit patterns: not run on one GPU], encode against the
-    # global amax — and the down shard's GEMM walks the all-gathered int8 blocks [8, 4096, 3584] in place.  Against the plain composition above, the re-quantisation of
-    # the gathered 4096 x 28672 activation on every rank (and the gather of bf16 gate AND up: 4 bytes per intermediate element instead of 1) is gone.
-    int8x = None
-    try:
-        from protoquant_amd.qtensor import quantize_with_amax, rowamax, silu_mul_quantize_with_amax, silu_mul_rowamax
-        ig = I // G
-        stacked = torch.randint(-127, 128, (G, M, ig), device=dev, dtype=torch.int8)          # stands for the all-gathered code blocks
-        stacked_scale = torch.rand(M, device=dev) * 1e-2 + 1e-4
-        # ... and the same exchange in front of `o` (ColumnShardedQLinear.forward_sharded_input): the rank's heads of the attention output [M, H / G] are quantised
-        # locally against the all-reduced amax and the int8 blocks gathered — instead of K1 on the gathered bf16 [M, H] on every rank
-        x_att = torch.randn(M, H // G, device=dev).to(torch.bfloat16)
-        stacked_o = torch.randint(-127, 128, (G, M, H // G), device=dev, dtype=torch.int8)
-
-        def fwd_int8():
-            for l in range(L):
-                qkv, o, gu, down = layers[l % NL]
-                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-                quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0])
-                pq.qlinear_s8_kslabs(stacked_o, stacked_scale, o.wq, o.ws, None, torch.bfloat16)
-                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(ig, dim=-1)
-                am = silu_mul_rowamax(g_, u_)
-                silu_mul_quantize_with_amax(g_, u_, am, out=stacked[0])
-                pq.qlinear_s8_kslabs(stacked, stacked_scale, down.wq, down.ws, None, torch.bfloat16)
-            return head(x_h)
-        fwd_int8(); torch.cuda.synchronize()
-        ti = []
-        for _ in range(3):
-            t0 = time.perf_counter(); fwd_int8(); torch.cuda.synchronize()
-            ti.append(time.perf_counter() - t0)
-        di = sorted(ti)[1]
-        XG = 153e9
-        hop_bf16 = 2 * (2.0 * M * ig) / XG + 2 * 2 * (2.0 * M * I * 2) / 5e12       # gather of the bf16 gate and up shards (one link per peer, all links at once) + their layout passes
-        hop_int8 = (4.0 * M) / XG + (1.0 * M * ig) / XG                             # all-reduce of M amax patterns (latency-bound in practice) + gather of the int8 blocks; no layout pass
-        # a layer's exchanges, modelled per rank (its shard over one direct link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s): the plain composition
-        # gathers every projection's bf16 output (q/k/v, o, gate and up, down); the int8 form gathers nothing after q/k/v (the rank's own heads consume them), int8 codes
-        # in front of o and down, and the bf16 outputs of o and down (the replicated residual stream)
-        link = lambda nbytes: nbytes / XG * 1e6      # noqa: E731
-        ex_bf16 = link(2.0 * M * (H + 2 * KVD) / G) + link(2.0 * M * H / G) + link(2.0 * M * 2 * I / G) + link(2.0 * M * H / G) \
-            + 2 * 2.0 * M * ((H + 2 * KVD) + H + 2 * I + H) / 5e12 * 1e6
-        ex_int8 = link(1.0 * M * H / G) + link(2.0 * M * H / G) + link(1.0 * M * I / G) + link(2.0 * M * H / G) + 2 * link(4.0 * M) + 2 * 2 * 2.0 * M * H / 5e12 * 1e6
-        int8x = {"ms_per_step": round(di * 1e3, 3), "value": round(ops / di / 1e12, 2), "unit": "TOPS", "us_per_layer": round((di - 0) / L * 1e6, 1),
-                 "modelled_exchange_us_per_layer": {"bf16_gather_of_every_output": round(ex_bf16, 1), "int8_code_exchange": round(ex_int8, 1),
-                                                    "model": "per rank: its shard over one direct xGMI link per peer at 153 GB/s, all 7 links at once, + layout passes at 5 TB/s; NOT measured, not overlapped with compute"},
-                 "what": "per layer: rmsnorm x2, qkv shard, row amax + encode of the LOCAL 1024 attention features, o shard on the stacked int8 blocks, gate+up shard, "
-                         "silu*mul row amax + encode on the LOCAL 3584 channels, down shard on the stacked int8 blocks (slabs walked in place)",
-                 "modelled_gate_up_to_down_hop_us": {"bf16_gather_of_gate_and_up_plus_layout": round(hop_bf16 * 1e6, 1), "int8_code_exchange": round(hop_int8 * 1e6, 1),
-                                                     "model": "bytes over one direct xGMI link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s; NOT measured"}}
-    except Exception as e:      # an extra figure must never lose the main line
-        print(f"[bench] int8-code exchange leg failed: {e}", file=sys.stderr)
-    # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (all NL weight sets in turn: HBM-fed like the step),
-    # with its share of the layer and — for the GEMMs —
-    # its fraction of the int8 peak: the per-shape account of the distance to 0.50 (DESIGN.md section 6)
-    per_shape = None
-    try:
-        def ev_graph(fn, n=8):
-            g = graph_of(fn, n)
-            g.replay(); torch.cuda.synchronize()
-            v = []
-            for _ in range(7):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); g.replay(); b.record(); b.synchronize()
-                v.append(a.elapsed_time(b) * 1e3 / n)
-            return sorted(v)[len(v) // 2]
-        qn = pq.rmsnorm_quantize(x_h, norm_w, 1e-5)
-        qh = pq.quantize(x_h)
-        qi = pq.quantize(x_i)
-        items = [("rmsnorm -> int8 (input of qkv; again for gate+up)", None, lambda l: pq.rmsnorm_quantize(x_h, norm_w, 1e-5), 2),
-                 ("fused qkv shard", (M, n_qkv, H), lambda l: layers[l][0](qn), 1),
-                 ("K1 of o's input (replicated attention output)", None, lambda l: pq.quantize(x_h), 1),
-                 ("o shard", (M, n_o, H), lambda l: layers[l][1](qh), 1),
-                 ("fused gate+up shard", (M, n_gu, H), lambda l: layers[l][2](qn), 1),
-                 ("K1 of down's input (the GATHERED silu(g)*u, 4096 x 28672)", None, lambda l: pq.quantize(x_i), 1),
-                 ("down shard", (M, n_down, I), lambda l: layers[l][3](qi), 1)]
-        # the int8-code exchange's three kernels (reported beside the account, not summed into it)
-        extra_items = []
-        if int8x is not None:
-            gu_out = layers[0][2](qn)
-            g0, u0 = gu_out.split(I // G, dim=-1)
-            am0 = silu_mul_rowamax(g0, u0)
-            extra_items = [("row amax + encode of the local attention features 4096 x 1024 (two launches)", None, lambda l: quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0]), 1),
-                           ("o shard on stacked int8 blocks [8, 4096, 1024]", (M, n_o, H), lambda l: pq.qlinear_s8_kslabs(stacked_o, stacked_scale, layers[l][1].wq, layers[l][1].ws, None, torch.bfloat16), 1),
-                           ("silu*mul row amax, local 4096 x 3584 (int8-code exchange)", None, lambda l: silu_mul_rowamax(g0, u0), 1),
-                           ("silu*mul encode against the global amax, local 4096 x 3584", None, lambda l: silu_mul_quantize_with_amax(g0, u0, am0, out=stacked[0]), 1),
-                           ("down shard on stacked int8 blocks [8, 4096, 3584]", (M, n_down, I), lambda l: pq.qlinear_s8_kslabs(stacked, stacked_scale, layers[l][3].wq, layers[l][3].ws, None, torch.bfloat16), 1)]
-        per_shape, tot = [], 0.0
-        for name, shp, fn, mult in items:
-            us = ev_graph(lambda: [fn(l) for l in range(NL)], 2) / NL
-            tot += us * mult
-            d = {"kernel": name, "us": round(us, 1), "per_layer": mult}
-            if shp is not None:
-                d["shape"] = "x".join(str(v) for v in shp)
-                d["frac_of_int8_peak"] = round(2.0 * shp[0] * shp[1] * shp[2] / us / 1e6 / PEAK_INT8_TOPS, 3)
-                d["dispatch"] = L_.lib().pq_gemm_variant_name(shp[0], shp[1], shp[2], shp[2], shp[2]).decode() + (" + workspace" if L_.lib().pq_qlinear_workspace_bytes(*shp) else "")
-            per_shape.append(d)
-        for d in per_shape:
-            d["share_of_layer"] = round(d["us"] * d["per_layer"] / tot, 3)
-        per_shape.append({"sum_per_layer_us": round(tot, 1), "step_per_layer_us": round(dt / L * 1e6, 1)})
-        # one layer of each composition replayed gap-free from a hipGraph over the NL weight sets (host-independent; the eager steps above carry Python's launch overhead)
-        def layer_plain(l):
-            qkv, o, gu, down = layers[l]
-            qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); o(x_h); gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)); down(x_i)
-        lg = {"column_sharded_bf16_gather": round(ev_graph(lambda: [layer_plain(l) for l in range(NL)], 2) / NL, 1)}
-        if int8x is not None:
-            def layer_int8(l):
-                qkv, o, gu, down = layers[l]
-                qkv(pq.rmsnorm_quantize(x_h, norm_w, 1e-5))
-                quantize_with_amax(x_att, rowamax(x_att), out=stacked_o[0])
-                pq.qlinear_s8_kslabs(stacked_o, stacked_scale, o.wq, o.ws, None, torch.bfloat16)
-                g_, u_ = gu(pq.rmsnorm_quantize(x_h, norm_w, 1e-5)).split(I // G, dim=-1)
-                silu_mul_quantize_with_amax(g_, u_, silu_mul_rowamax(g_, u_), out=stacked[0])
-                pq.qlinear_s8_kslabs(stacked, stacked_scale, down.wq, down.ws, None, torch.bfloat16)
-            lg["int8_code_exchange"] = round(ev_graph(lambda: [layer_int8(l) for l in range(NL)], 2) / NL, 1)
-            int8x["us_per_layer_graph"] = lg["int8_code_exchange"]
-        per_shape.append({"layer_us_from_hipgraph": lg})
-        if extra_items:
-            ex = []
-            for name, shp, fn, mult in extra_items:
-                us = ev_graph(lambda: [fn(l) for l in range(NL)], 2) / NL
-                d = {"kernel": name, "us": round(us, 1)}
-                if shp is not None:
-                    d["frac_of_int8_peak"] = round(2.0 * shp[0] * shp[1] * shp[2] / us / 1e6 / PEAK_INT8_TOPS, 3)
-                ex.append(d)
-            int8x["kernels"] = ex
-    except Exception as e:
-        print(f"[bench] per-shape leg failed: {e}", file=sys.stderr)
-    # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
-    gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
-    t_gather = gathered * (G - 1) / G / (7 * 153e9)
-    emit_json({"metric": "int8 TOPS per GPU, Llama-3-70B column-sharded over 8 GPUs: one rank's linears at M=4096 (exchange modelled)",
-                      "value": round(ops / dt / 1e12, 2), "unit": "TOPS", "n_gpus": 1, "steps": len(ts), "warmup": 2, "ms_per_step": round(dt * 1e3, 3),
-                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-                      "config": {"workload": f"one of 8 ranks of Llama-3-70B ({L} layers + lm_head), weights column-sharded: per-GPU shards 4096x{n_qkv}x8192 (fused qkv), "
-                                             f"4096x{n_o}x8192 (o), 4096x{n_gu}x8192 (fused gate+up), 4096x{n_down}x28672 (down), 4096x{n_head}x8192 (lm_head) (BASELINE configs[4])",
-                                 "int8_ops_per_rank": ops, "gathered_bytes_per_pass": gathered,
-                                 "modelled_allgather_ms": round(t_gather * 1e3, 2), "row_sharded_pairing": pairing, "int8_code_exchange": int8x, "per_shape": per_shape,
-                                 "model": "all-gather after dequant of every linear's bf16 output; a rank receives 7/8 of it over 7 xGMI links x 153 GB/s (fully connected, direct); NOT measured"},
-                      "roofline": {"bound": "mfma", "achieved": round(ops / dt / 1e12, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                                   "frac": round(ops / dt / 1e12 / PEAK_INT8_TOPS, 4), "traffic": None,
-                                   "note": "one rank's compute only: every activation quantisation (RMSNorm fused for q/k/v and gate/up) + the shard GEMMs"},
-                      "cpu_baseline": None})
-
-
-class _Watchdog:
-    """A collective that hangs cannot be cancelled from inside the process.  Every leg that drives the native exchange (a second RCCL communicator inside
-    libpq_rccl.so) therefore runs with this timer armed FOR THAT LEG ONLY (armed just before the leg's first native collective, cancelled when the leg's result is
-    recorded — ADVICE r4: the round-4 timer covered the whole rest of the benchmark): if it fires, rank 0 prints the best line the legs that DID finish and verify
-    support, with top-level "native_exchange": "hung" and the leg's name, and every rank leaves with status 0 (a fresh exit, no re-exec)."""
-
-    def __init__(self, rank, compose):
-        import threading
-        self._threading, self.rank, self.compose = threading, rank, compose
-        self.lock, self.done, self.timer, self.leg = threading.Lock(), False, None, None
-
-    def arm(self, leg, seconds):
-        self.disarm()
-        self.leg = leg
-        self.timer = self._threading.Timer(seconds, self._fire, args=(leg, seconds))
-        self.timer.daemon = True
-        self.timer.start()
-
-    def disarm(self):
-        if self.timer is not None:
-            self.timer.cancel()
-            self.timer = None
-
-    def _fire(self, leg, seconds):
-        with self.lock:
-            if self.done:
-                return
-            self.done = True
-            line = None
-            try:
-                line = self.compose(hung_leg=leg, timeout=seconds)
-            except Exception as e:
-                print(f"[bench] rank {self.rank}: composing the line after a hang failed: {e}", file=sys.stderr)
-            print(f"[bench] rank {self.rank}: the native RCCL leg '{leg}' did not finish within {seconds:.0f} s — "
-                  + ("printing the best verified line of the legs that finished" if line else "no finished leg either"), file=sys.stderr)
-            if self.rank == 0 and line is not None:
-                emit_json(line)
-            sys.stderr.flush()
-            os._exit(0 if line is not None else 3)
-
-
-def run_tp(args, world, rank, dev, dist):
-    """north_star's split of the headline qlinear over `world` ranks (one process per GPU): W column-sharded over the output channels, the activation
-    replicated (every rank runs K1 itself), ONE all-gather of the bf16 output shards per step.  The repo holds several forms of that exchange (DESIGN.md §6);
-    each is a LEG here: timed by the same protocol (W warm-up steps + warm-up by time, R blocks of exactly K steps between barrier + synchronize, max over ranks,
-    median block), replayed whole from a hipGraph where it can be captured, and VERIFIED — every rank compares the y it ends up holding, bit for bit, with the
-    unsharded qlinear it computes itself from the full weight.  The headline `value` is the fastest leg that finished AND verified; every leg is listed under
-    `legs`.  Legs:
-      torch_plain / torch_transposed   torch.distributed's own all-gather (the path every PyTorch job uses), issued eagerly behind the compute graph — measured
-                                       FIRST: they are the line a hung native collective falls back to
-      native_plain                     pq_allgather_cols_v: ncclAllGather into a stacked workspace + layout kernel
-      native_transposed                pq_qlinear_s8_t + pq_allgather_rows_t: transposed shards, ONE contiguous ncclAllGather, no layout pass (SURVEY.md §8(e) option 1)
-      native_overlap{2,4,8}            row blocks: each block's exchange (pq_allgather_cols_rows_async, the communicator's side stream) runs under the next block's
-                                       GEMM; pq_comm_join at the end of the step (SURVEY.md:303 "chunked along M and overlapped with K3")"""
-    import protoquant_amd as pq
-    from protoquant_amd import _lib as L
-    from protoquant_amd.sharded import shard_bounds, gather_columns
-    lib = L.lib()
-    M, N, K = args.M, args.N, args.K
-    st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
-    med = lambda v: sorted(v)[len(v) // 2]                   # noqa: E731
-    K_steps, R, PG = max(1, args.steps), max(1, args.repeats), 20
-    lo, hi = shard_bounds(N, world, rank)
-    n_local = hi - lo
-    equal = N % world == 0
-
-    def fence():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    def all_min(flag):
-        t = torch.tensor([1 if flag else 0], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t.item()))
-
-    def all_max(v):
-        t = torch.tensor([v], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def ev_us(g, n):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); g.replay(); b.record(); b.synchronize()
-        return a.elapsed_time(b) * 1e3 / n
-
-    # ---- synthetic data (SURVEY §8d), seeded on the CPU generator so every rank and every box agree.  Every rank holds the FULL weight as well: it is what
-    # the verification computes the unsharded qlinear from (per-channel quantisation is row-local: the rank's shard is a row block of the full codes).
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
-    gw = torch.Generator().manual_seed(4321)
-    qw = pq.quantize((torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16).to(dev))
-    wq_full, ws_full = qw.int_data, qw.scale
-    wq, ws = wq_full[lo:hi].clone(), ws_full[lo:hi].clone()       # the rank's shard (own allocations: aligned bases for any split)
-    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
-    xs = torch.empty((M,), dtype=torch.float32, device=dev)
-    y_loc = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
-    yt_loc = torch.empty((n_local, M), dtype=torch.bfloat16, device=dev)
-    y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    yt_full = torch.empty((N, M), dtype=torch.bfloat16, device=dev)
-
-    def wspace(nbytes):
-        return torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev), nbytes
-
-    def k1():
-        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
-
-    def gemm_rows(m0, m1, wsp, wb, w=None, wsc=None, out=None, ldo=None, n=None):
-        w = wq if w is None else w; wsc = ws if wsc is None else wsc
-        out = y_loc if out is None else out; n = n_local if n is None else n; ldo = n if ldo is None else ldo
-        L.check(lib.pq_qlinear_s8(xq.data_ptr() + m0 * K, K, xs.data_ptr() + 4 * m0, w.data_ptr(), K, wsc.data_ptr(), None,
-                                  out.data_ptr() + 2 * m0 * ldo, ldo, 0, m1 - m0, n, K, wsp.data_ptr() if wb else None, wb, st()), "pq_qlinear_s8")
-    wsp_l, wb_l = wspace(lib.pq_qlinear_workspace_bytes(M, n_local, K))
-    wsp_t, wb_t = wspace(lib.pq_qlinear_t_workspace_bytes(M, n_local, K))
-
-    def k3():
-        gemm_rows(0, M, wsp_l, wb_l)
-
-    def k3t():
-        L.check(lib.pq_qlinear_s8_t(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, yt_loc.data_ptr(), M, 0,
-                                    M, n_local, K, wsp_t.data_ptr() if wb_t else None, wb_t, st()), "pq_qlinear_s8_t")
-
-    # the unsharded qlinear on this rank: the bits every leg must reproduce
-    y_ref = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    wsp_f, wb_f = wspace(lib.pq_qlinear_workspace_bytes(M, N, K))
-    k1(); gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)
-    torch.cuda.synchronize()
-    y_ref_bits = y_ref.view(torch.int16)
-
-    # ---- per-kernel durations (no collective): the rank's shard GEMM (the `roofline` kernel), K1 cache-resident and HBM-fed, the compute step
-    gk1, gk3, gst = graph_of(k1, PG), graph_of(k3, PG), graph_of(lambda: (k1(), k3()), PG)
-    for g_ in (gk1, gk3, gst):
-        g_.replay()
-    torch.cuda.synchronize()
-    t_end = time.perf_counter() + min(args.warmup_seconds, 1.0)
-    while time.perf_counter() < t_end:
-        gst.replay(); torch.cuda.synchronize()
-    tk1, tk3, tst = [], [], []
-    for _ in range(max(R, 20)):
-        tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
-    t_gemm, t_k1_hot, t_stepc = med(tk3), med(tk1), med(tst)
-    n_rot = max(2, -(-600 * 2**20 // (3 * M * K)))
-    rot = [(torch.randn(M, K, device=dev).to(torch.bfloat16), torch.empty((M, K), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
-           for _ in range(n_rot)]
-
-    def k1_rot():
-        for xr_, qr_, sr_ in rot:
-            L.check(lib.pq_quant_rowwise(xr_.data_ptr(), 0, M, K, K, qr_.data_ptr(), K, sr_.data_ptr(), st()), "pq_quant_rowwise")
-    g_rot = graph_of(k1_rot, 2)
-    g_rot.replay(); torch.cuda.synchronize()
-    t_k1 = med([ev_us(g_rot, 2 * n_rot) for _ in range(15)])
-    del rot, g_rot, gk1, gk3, gst
-    consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)
-    if not consistent:      # several ranks share one host and one power envelope: a multi-GPU line is never lost to this check, it carries the flag
-        print(f"[bench] WARNING (rank {rank}): GEMM {t_gemm:.2f} us + K1 {t_k1_hot:.2f} (cache-resident) .. {t_k1:.2f} us (HBM) vs compute step {t_stepc:.2f} us", file=sys.stderr)
-
-    # ---- the legs
-    class Leg:
-        def __init__(self, name, exchange, compute, comm, result, clear, native, capturable, what, chunks=1):
-            self.name, self.exchange, self.compute, self.comm, self.result, self.clear = name, exchange, compute, comm, result, clear
-            self.native, self.capturable, self.what, self.chunks = native, capturable, what, chunks
-
-        def step(self):
-            self.compute(); self.comm()
-
-    def tg_plain():
-        y_full.copy_(gather_columns(y_loc, N))
-
-    def tg_t():
-        if equal:
-            dist.all_gather_into_tensor(yt_full.view(-1), yt_loc.view(-1))
-        else:
-            from protoquant_amd.sharded import gather_rows_t
-            yt_full.copy_(gather_rows_t(yt_loc, N))
-    clear_rows = lambda: (y_full.zero_(), y_loc.zero_())       # noqa: E731
-    clear_t = lambda: (yt_full.zero_(), yt_loc.zero_())        # noqa: E731
-    legs = [Leg("torch_plain", f"torch.distributed all_gather_into_tensor ({args.backend}) + layout pass", lambda: (k1(), k3()), tg_plain, lambda: y_full, clear_rows, False, False,
-                "K1 + shard GEMM from a hipGraph, the collective issued eagerly behind each step"),
-            Leg("torch_transposed", f"pq_qlinear_s8_t + torch.distributed all_gather_into_tensor ({args.backend}) straight into y^T[N, M], no layout pass", lambda: (k1(), k3t()), tg_t,
-                lambda: yt_full.t(), clear_t, False, False, "transposed shards: the gather is contiguous; y is the column-major view y^T.t() (same bits)")]
-    rg, native_state = None, "not_attempted"
-    want_native = args.backend == "nccl" and not args.torch_gather
-    results, order = {}, []
-    shared = {"native_state": native_state}
-
-    def leg_model(leg, t_comp):
-        """DESIGN.md §6's model of this leg for this G: the rank's MEASURED compute, the all-gather at the point-to-point link rate (every peer's shard arrives over its
-        own xGMI link, ~153 GB/s each, all links busy at once) and, for the row-major forms, the layout pass (reads + writes 2 M N bytes at ~5 TB/s)."""
-        XGMI_LINK_GBS, LAYOUT_TBS = 153.0, 5.0
-        shard_bytes = 2 * M * n_local
-        ag = shard_bytes / (XGMI_LINK_GBS * 1e3) if world > 1 else 2 * M * N / (LAYOUT_TBS * 1e6)     # world 1: a device-local copy
-        lay = 0.0 if "transposed" in leg.name else 2 * (2 * M * N) / (LAYOUT_TBS * 1e6)
-        C = leg.chunks
-        if C > 1:           # pipeline of C row blocks: the first block's GEMM and the last block's exchange are exposed, the rest runs at the slower of the two
-            c, e = (t_comp - t_k1_hot) / C, (ag + lay) / C
-            step = t_k1_hot + c + (C - 1) * max(c, e) + e
-        else:
-            step = t_comp + ag + lay
-        return {"compute_us": round(t_comp, 2), "allgather_us": round(ag, 2), "layout_pass_us": round(lay, 2), "step_us": round(step, 2),
-                "assumptions": f"per-rank shard {shard_bytes} B over one direct xGMI link per peer at {XGMI_LINK_GBS:.0f} GB/s, all {max(world - 1, 1)} links concurrently; "
-                               f"layout pass at {LAYOUT_TBS:.0f} TB/s; " + (f"{C} row blocks, exchange of block i under the GEMM of block i+1" if C > 1 else "no overlap of exchange and compute")
-                               + " (DESIGN.md §6)"}
-
-    def run_leg(leg):
-        """time + verify one leg; returns its record"""
-        rec = {"exchange": leg.exchange, "what": leg.what, "native": leg.native, "verified": False}
-        S, g_main, g_rem, in_graph = 1, None, None, False
-        leg.step(); torch.cuda.synchronize()                      # (allocates exchange workspaces outside any capture)
-        if leg.capturable and not args.no_graph:
-            try:
-                S = min(K_steps, 20)
-                g_main = graph_of(leg.step, S)
-                if K_steps % S:
-                    g_rem = graph_of(leg.step, K_steps % S)
-                in_graph = True
-            except Exception as e:
-                print(f"[bench] leg {leg.name}: capturing the exchange into the step graph failed ({e}); collective issued eagerly behind each step", file=sys.stderr)
-            in_graph = all_min(in_graph)                            # every rank must replay the same thing
-            if not in_graph:
-                g_main = g_rem = None
-        g_comp = None
-        if not in_graph:
-            S = 1
-            if not args.no_graph:
-                g_comp = graph_of(leg.compute, 1)
-
-        def run_steps(n):
-            if in_graph:
-                for _ in range(n // S):
-                    g_main.replay()
-                if n % S:
-                    (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(leg.step, n % S)).replay()
-                return
-            for _ in range(n):
-                if g_comp is not None:
-                    g_comp.replay()
-                else:
-                    leg.compute()
-                leg.comm()
-        run_steps(args.warmup)
-        fence()
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < args.warmup_seconds:
-            run_steps(K_steps)
-            torch.cuda.synchronize()
-        fence()
-        blocks, host_enq = [], []
-        for _ in range(R):
-            fence()
-            t0 = time.perf_counter()
-            run_steps(K_steps)
-            host_enq.append(time.perf_counter() - t0)
-            torch.cuda.synchronize()
-            blocks.append(all_max(time.perf_counter() - t0))
-        blocks.sort()
-        dt = blocks[len(blocks) // 2]
-        # verification: outputs cleared, exactly the timed step once more, then every rank compares what it holds with its own unsharded qlinear
-        leg.clear(); torch.cuda.synchronize()
-        run_steps(S if in_graph else 1)
-        torch.cuda.synchronize()
-        got = leg.result()
-        same = tuple(got.shape) == (M, N) and bool(torch.equal(got.contiguous().view(torch.int16), y_ref_bits))
-        rec["verified"] = all_min(same)
-        if not same:
-            print(f"[bench] rank {rank}: leg {leg.name} does NOT reproduce the unsharded qlinear", file=sys.stderr)
-        # the leg's compute alone (K1 + its GEMM launches) and its exchange alone, gap-free from their own graphs where capturable
-        t_comp = t_exch = None
-        try:
-            gc_ = graph_of(leg.compute, PG)
-            gc_.replay(); torch.cuda.synchronize()
-            t_comp = med([ev_us(gc_, PG) for _ in range(9)])
-            del gc_
-            fence()
-            if in_graph:
-                ge_ = graph_of(leg.comm, PG)
-                ge_.replay(); fence()
-                v = med([ev_us(ge_, PG) for _ in range(9)])
-                del ge_
-            else:
-                def ex_eager():
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(PG):
-                        leg.comm()
-                    b.record(); b.synchronize()
-                    return a.elapsed_time(b) * 1e3 / PG
-                ex_eager(); fence()
-                v = med([ex_eager() for _ in range(5)])
-            t_exch = all_max(v)
-            fence()
-        except Exception as e:
-            print(f"[bench] leg {leg.name}: compute / exchange-only timing failed: {e}", file=sys.stderr)
-        host_us = med(host_enq) / K_steps * 1e6
-        step_us = dt / K_steps * 1e6
-        rec.update({"value": round(2.0 * M * N * K * K_steps / dt / 1e12, 2), "unit": "TOPS", "ms_per_step": round(dt / K_steps * 1e3, 5),
-                    "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
-                    "collective_in_graph": in_graph,
-                    "launch": (f"hipgraph x{S} steps/replay, exchange captured in the graph" if in_graph else
-                               ("hipgraph x1 step/replay (compute), collective eager behind each step" if g_comp is not None else "eager")),
-                    "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool((not in_graph) and host_us > 0.9 * step_us),
-                    "compute_us": round(t_comp, 2) if t_comp is not None else None, "exchange_us": round(t_exch, 2) if t_exch is not None else None})
-        if t_comp is not None:
-            rec["modelled"] = leg_model(leg, t_comp)
-            rec["measured_minus_modelled_us"] = round(step_us - rec["modelled"]["step_us"], 2)
-        return rec
-
-    def compose(hung_leg=None, timeout=None):
-        """the ONE JSON line from whatever has finished so far (called at the end, or by the watchdog)"""
-        done = {n: results[n] for n in order if n in results}
-        ok = [n for n in done if done[n]["verified"] and "value" in done[n]]
-        timed = [n for n in done if "ms_per_step" in done[n]]
-        if not timed:
-            return None
-        head = min(ok, key=lambda n: done[n]["ms_per_step"]) if ok else None
-        h = done[head] if head else done[timed[0]]          # (no verified leg: the line carries value 0 and verified = false)
-        variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
-        kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
-                 "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
-        if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
-            kname += " split-K + splitk_reduce_epilogue"
-        gemm_ops, gemm_bytes, k1_bytes = 2.0 * M * n_local * K, M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local), 3 * M * K + 4 * M
-        out = {
-            "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
-            "value": h["value"] if head else 0.0, "unit": "TOPS", "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
-            "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
-            "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
-                       "parallelism": f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant",
-                       "headline_leg": head, "exchange": h["exchange"], "launch": h["launch"], "collective_in_graph": h["collective_in_graph"],
-                       "rccl_ranks": shared.get("rccl_ranks", dist.get_world_size()), "native": bool(h["native"]),
-                       "repeats": R, "timed": f"per leg: median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks); headline = the fastest "
-                                              "leg that finished AND reproduced the unsharded qlinear bit for bit on every rank",
-                       "warmup_seconds": args.warmup_seconds, "gemm_variant": variant},
-            "verified": bool(head is not None), "ms_per_step_min": h["ms_per_step_min"], "ms_per_step_max": h["ms_per_step_max"],
-            "legs": done, "native_exchange": "hung" if hung_leg else shared["native_state"],
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(gemm_ops / t_gemm / 1e6, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                         "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4), "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_min": round(min(tk3), 2),
-                         "how": f"the rank's shard GEMM {M}x{n_local}x{K}: median of {len(tk3)} hipGraph replays of {PG} back-to-back launches, HIP events on the launch stream",
-                         "traffic": None, "algorithmic_bytes": gemm_bytes},
-            "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4), "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes,
-                           "how": f"gap-free hipGraph replays rotating over {n_rot} distinct input/output pairs: every launch is HBM-fed",
-                           "in_step_us": round(t_stepc - t_gemm, 2), "cache_resident_replay_us": round(t_k1_hot, 2)},
-            "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
-            "host_enqueue_us_per_step": h["host_enqueue_us_per_step"], "host_bound": h["host_bound"],
-            "compute_us": h["compute_us"], "exchange_us": h["exchange_us"], "exchange_bytes_received_per_rank": 2 * M * (N - n_local),
-            "cpu_baseline": shared.get("cpu_baseline"),
-        }
-        if "modelled" in h:
-            out["modelled"] = h["modelled"]
-            out["config"]["modelled_step_us"] = h["modelled"]["step_us"]
-            out["measured_minus_modelled_us"] = h["measured_minus_modelled_us"]
-        if "torch_plain" in done and "ms_per_step" in done["torch_plain"]:
-            out["torch_distributed_exchange_ms_per_step"] = done["torch_plain"]["ms_per_step"]
-        if "dp" in shared:
-            out["dp"] = shared["dp"]
-        if hung_leg:
-            out["hung_leg"] = hung_leg
-            out["fallback"] = (f"the native exchange leg '{hung_leg}' (libpq_rccl.so) did not finish within {timeout:.0f} s: the line is the fastest verified leg among those that "
-                               "finished before it")
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                tr = json.load(open(tj))
-                if (M, n_local, K) == (4096, 4096, 4096):
-                    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr.get("gemm_hbm_bytes_per_launch"), tr.get("source")
-                else:       # the rank's shard GEMM is another shape: PMC passes per shard width (tools/pmc_traffic_shards.sh)
-                    out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch_by_shape", {}).get(f"{M}x{n_local}x{K}")
-                    out["roofline"]["traffic_source"] = tr.get("source_by_shape") if out["roofline"]["traffic"] else None
-            except Exception:
-                pass
-        return out
-
-    dog = _Watchdog(rank, compose)
-    # the torch.distributed legs first: the net under everything that follows
-    for leg in legs:
-        order.append(leg.name)
-        try:
-            results[leg.name] = run_leg(leg)
-        except Exception as e:
-            print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
-            results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": False}
-
-    emit_marker("safe")                                  # (to the rank's supervisor: the torch.distributed legs are in)
-    if rank == 0:
-        emit_json(compose(), final=False)
-    if want_native and args.simulate_native_crash:
-        import signal
-        sys.stderr.flush()
-        os.kill(os.getpid(), signal.SIGSEGV)
-    if want_native:
-        def boot():
-            from protoquant_amd.sharded import RcclColumnGather
-            return RcclColumnGather()
-        dog.arm("communicator bootstrap", args.native_timeout)
-        if args.simulate_native_hang:
-            while True:
-                time.sleep(1.0)
-        try:
-            rg = boot()
-        except Exception as e:
-            print(f"[bench] native RCCL exchange unavailable ({e})", file=sys.stderr)
-            rg = None
-        if not all_min(rg is not None):          # every rank must take the same path
-            rg = None
-        dog.disarm()
-        shared["native_state"] = "ok" if rg is not None else "unavailable"
-    if rg is not None:
-        shared["rccl_ranks"] = rg.comm_ranks()
-        nat = [Leg("native_plain", "libpq_rccl.so pq_allgather_cols_v (ncclAllGather + layout kernel)", lambda: (k1(), k3()), lambda: rg.gather_into(y_loc, y_full, N),
-                   lambda: y_full, clear_rows, True, True, "the whole step (K1, shard GEMM, ncclAllGather, layout kernel) in one hipGraph"),
-               Leg("native_transposed", "libpq_rccl.so pq_qlinear_s8_t + pq_allgather_rows_t (one contiguous ncclAllGather, no layout kernel)", lambda: (k1(), k3t()),
-                   lambda: rg.gather_t(yt_loc, N, out=yt_full), lambda: yt_full.t(), clear_t, True, True,
-                   "transposed shards gathered in place; y is the column-major view y^T.t() (same bits)")]
-        for C in (2, 4, 8):
-            if M // C < 256:
-                continue
-            bounds = [shard_bounds(M, C, c) for c in range(C)]
-            wsp_c, wb_c = wspace(max(lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K) for m0, m1 in bounds))
-
-            def comp_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
-                k1()
-                for m0, m1 in bounds:
-                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
-
-            def comm_c(bounds=bounds):
-                for m0, m1 in bounds:
-                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
-                rg.join(dev)
-
-            def step_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
-                k1()
-                for m0, m1 in bounds:
-                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
-                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
-                rg.join(dev)
-            lg = Leg(f"native_overlap{C}", f"libpq_rccl.so pq_allgather_cols_rows_async x{C} row blocks on the communicator's side stream + pq_comm_join", comp_c, comm_c,
-                     lambda: y_full, clear_rows, True, True, f"{C} row blocks: the exchange of block i runs under the GEMM of block i+1; the whole step in one hipGraph", chunks=C)
-            lg.step = step_c
-            nat.append(lg)
-        for leg in nat:
-            order.append(leg.name)
-            dog.arm(leg.name, args.native_timeout)
-            if args.simulate_leg_hang == leg.name:
-                while True:
-                    time.sleep(1.0)
-            try:
-                results[leg.name] = run_leg(leg)
-            except Exception as e:
-                print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
-                results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": True}
-            ok_everywhere = all_min("error" not in results[leg.name])   # (still under the leg's watchdog: a rank that raised is out of step with the others' collectives)
-            dog.disarm()
-            if rank == 0:
-                with dog.lock:
-                    if not dog.done:
-                        emit_json(compose(), final=False)                # provisional: what the supervisor prints if a later leg kills this process
-            if not ok_everywhere:                                       # stop trying native legs
-                shared["native_state"] = "failed"
-                break
-
-    if not args.no_dp_leg:
-        # extra key: the same ranks as independent replicas over tokens (weak scaling, replicated weights, no collective), short
-        try:
-            gd = graph_of(lambda: (k1(), gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)), PG)
-            for _ in range(10):
-                gd.replay()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(25):
-                gd.replay()
-            torch.cuda.synchronize()
-            d = all_max(time.perf_counter() - t0)
-            shared["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / d / 1e12, 2), "unit": "TOPS", "scaling": "weak",
-                            "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
-        except Exception as e:
-            print(f"[bench] dp leg failed: {e}", file=sys.stderr)
-    if rank == 0 and not args.no_cpu_baseline:
-        # after every timed region; the other ranks wait at the barrier below (they hold no GPU work)
-        try:
-            shared["cpu_baseline"] = cpu_baseline(M, N, K, budget_s=20.0)
-        except Exception as e:
-            print(f"[bench] cpu baseline failed: {e}", file=sys.stderr)
-    with dog.lock:
-        if dog.done:
-            return
-        dog.done = True
-        dog.disarm()
-        if rank == 0:
-            emit_json(compose())
-    if rg is not None:
-        try:
-            rg.close()
-        except Exception:
-            pass
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-_JSON_FD = None
-
-
-def _claim_stdout():
-    """The driver reads ONE JSON line from stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when
-    a communicator is created, flushed at exit): from here on file descriptor 1 goes to stderr, and the JSON line alone is written to
-    the original stdout (emit_json)."""
-    global _JSON_FD
-    if _JSON_FD is None:
-        sys.stdout.flush()
-        _JSON_FD = os.dup(1)
-        os.dup2(2, 1)
-
-
-def _pipe_fd():
-    v = os.environ.get("PQ_BENCH_PIPE")
-    return int(v) if v else None
-
-
-def emit_json(obj, final=True):
-    """The ONE JSON line.  Under a supervisor (tp runs over more than one rank: supervise()) it goes to the supervisor's pipe as a record — provisional lines too,
-    so that the best line so far survives a worker that dies — and the supervisor prints the last one; otherwise straight to the original stdout."""
-    fd = _pipe_fd()
-    if fd is not None:
-        os.write(fd, (json.dumps({"final": bool(final), "line": obj}) + "\n").encode())
-        return
-    if not final:
-        return
-    data = (json.dumps(obj) + "\n").encode()
-    if _JSON_FD is None:
-        sys.stdout.write(data.decode()); sys.stdout.flush()
-    else:
-        os.write(_JSON_FD, data)
-
-
-def emit_marker(name):
-    fd = _pipe_fd()
-    if fd is not None:
-        os.write(fd, (json.dumps({"marker": name}) + "\n").encode())
-
-
-def supervisor_verdict(records, rc):
-    """What a rank's supervisor does with what its worker reported (raw pipe lines) and how the worker ended: (the line to print or None, the exit status, whether the
-    worker got past the safe legs).  The last line record wins; a line that is not the worker's final one is marked "native_exchange": "crashed"; a worker that died
-    after the torch.distributed legs were in does not fail the rank."""
-    last, final, safe = None, False, False
-    for raw in records:
-        try:
-            rec = json.loads(raw)
-        except ValueError:
-            continue                           # (a record cut short by the worker's death)
-        if not isinstance(rec, dict):
-            continue
-        if "marker" in rec:
-            safe = safe or rec["marker"] == "safe"
-        elif rec.get("line") is not None:
-            last, final = rec["line"], bool(rec.get("final"))
-    if last is not None and not final:
-        last["native_exchange"] = "crashed"
-        last["fallback"] = (f"the rank's worker process ended (status {rc}) before its final line: this is the fastest verified leg among those that had finished — "
-                            "printed by the rank's supervisor process")
-    return last, (0 if (rc == 0 or safe) else (rc if rc > 0 else 1)), safe
-
-
-def supervise(args):
-    """tp over more than one rank: THIS process (one per rank, started by torch.distributed.run) never touches the GPU.  It starts the real rank as a child — same
-    command, same environment, plus a pipe — and relays what the child reports: rank 0's worker sends every line it could print so far (after the torch.distributed
-    legs, after each native leg, the final one), every worker sends a marker once the torch.distributed legs are in.  However the child ends — normally, by its
-    watchdog, or KILLED by a fault inside a native collective (a segfault or a GPU memory fault cannot be caught inside the process) — rank 0's supervisor prints the
-    last line it holds ("native_exchange": "crashed" when the child died before its final line) and every supervisor whose child got as far as the safe legs exits 0:
-    the first multi-GPU run is one shot, and a verified torch.distributed line must survive anything the native exchange does."""
-    import subprocess
-    rfd, wfd = os.pipe()
-    env = dict(os.environ, PQ_BENCH_WORKER="1", PQ_BENCH_PIPE=str(wfd))
-    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, pass_fds=(wfd,))
-    os.close(wfd)
-    with os.fdopen(rfd, "r") as pipe:
-        records = list(pipe)                   # ends when the child (and everything that inherited the pipe) is gone
-    rc = child.wait()
-    rank = int(os.environ.get("RANK", "0"))
-    line, code, safe = supervisor_verdict(records, rc)
-    if rank == 0 and line is not None:
-        sys.stdout.write(json.dumps(line) + "\n"); sys.stdout.flush()
-    if rc != 0:
-        print(f"[bench] rank {rank}: worker ended with status {rc}" + ("; the line measured before it is kept" if safe else ""), file=sys.stderr)
-    sys.exit(code)
-
-
-def self_launch(args):
-    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE / RANK in the environment): start the N ranks ourselves, exactly as the
-    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>`),
-    relay rank 0's ONE JSON line and exit with the launcher's status.  Runs BEFORE anything in this process has touched the GPU (`import torch`
-    does not), and starts CHILD processes — never a re-exec of a process that initialised HIP."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    print(f"[bench] no launcher in the environment: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)          # stderr passes through
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    for l in r.stdout.splitlines():
-        if not l.strip().startswith("{"):
-            print(l, file=sys.stderr)
-    if r.returncode != 0 or len(lines) != 1:
-        print(f"[bench] the {args.gpus}-rank launch failed (exit {r.returncode}, {len(lines)} JSON lines)", file=sys.stderr)
-        sys.exit(r.returncode or 1)
-    sys.stdout.write(lines[0] + "\n"); sys.stdout.flush()
-    sys.exit(0)
 
 
 def main():
     args = parse()
+    hooks = test_hooks()           # (tests only, from the environment: benchlib.common.test_hooks)
+    script = os.path.abspath(__file__)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        return self_launch(args)
-    tp_ranks = args.workload == "qlinear" and args.mode != "dp" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.supervise and args.mode == "tp"))
+        return self_launch(args, script)
+    tp_ranks = args.workload == "qlinear" and args.mode != "dp" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (hooks.get("supervise") and args.mode == "tp"))
     if tp_ranks and not os.environ.get("PQ_BENCH_WORKER") and not args.no_supervisor:
-        return supervise(args)          # (before anything here has touched the GPU: `import torch` does not)
+        return supervise(args, script)          # (before anything here has touched the GPU: `import torch` does not)
     _claim_stdout()
-    if args.workload == "llama8b":
-        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b is a 1-GPU measurement"
-        return run_llama8b(args) if args.tokens > 512 else run_llama8b_linears(args)
-    if args.workload == "llama70b-shard":
-        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama70b-shard plays one rank on one GPU"
-        return run_llama70b_shard(args)
-    if args.workload == "llama8b-linears":
-        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload llama8b-linears is a 1-GPU measurement"
-        return run_llama8b_linears(args)
-    if args.workload == "mlp":
-        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload mlp is a 1-GPU measurement"
-        return run_mlp(args)
+    if args.workload != "qlinear":
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--workload {args.workload} is a 1-GPU measurement"
+        from benchlib import workloads as W
+        if args.workload == "llama8b":
+            return W.run_llama8b(args, oracle_module) if args.tokens > 512 else W.run_llama8b_linears(args, oracle_module)
+        return {"llama70b-shard": W.run_llama70b_shard, "llama8b-linears": W.run_llama8b_linears, "mlp": W.run_mlp}[args.workload](args, oracle_module)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1352,7 +128,8 @@ def main():
     # the whole qlinear on its own batch (weak scaling, no collective): below; reported as the extra key "dp" in tp runs.
     mode = args.mode if args.mode != "auto" else ("tp" if world > 1 else "dp")
     if mode == "tp":
-        return run_tp(args, world, rank, dev, dist)
+        from benchlib.tp import run_tp
+        return run_tp(args, world, rank, dev, dist, cpu_fn=cpu_baseline)
 
     import protoquant_amd as pq
     from protoquant_amd import _lib as L
@@ -1469,7 +246,6 @@ def main():
     tk1, tk3, tst = [], [], []
     for _ in range(max(R, 20)):
         tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
-    med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
     t_gemm, t_k1, t_stepc = med(tk3), med(tk1), med(tst)
     # K1 against HBM, not against the caches: replayed on ONE input, K1's 32-MB read set is served by the L2s (each XCD re-reads
     # the same eighth of x every launch, and write-through stores leave nothing dirty to evict it) and the 256-MB Infinity Cache —
@@ -1580,21 +356,10 @@ def main():
         "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
         "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool(host_bound),
     }
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
-        try:
-            tr = json.load(open(tj))
-            if (M, N, K) == (4096, 4096, 4096):
-                out["roofline"]["traffic"] = tr.get("gemm_hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = tr.get("source")
-            else:
-                by = tr.get("gemm_hbm_bytes_per_launch_by_shape", {})
-                out["roofline"]["traffic"] = by.get(f"{M}x{N}x{K}")
-                out["roofline"]["traffic_source"] = tr.get("source_by_shape") if out["roofline"]["traffic"] else None
-        except Exception:
-            pass
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic_for((M, N, K))
     if world == 1 and not args.no_gpu_context:
         k1(); k3(); torch.cuda.synchronize()
+        from benchlib.context import gpu_context
         out["gpu_context"] = gpu_context(x, wq, ws, y, med)
         t_pipe = out["gpu_context"].get("torch_rocm_int8_pipeline_us")
         if t_pipe:

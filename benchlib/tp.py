@@ -1,0 +1,504 @@
+"""benchlib.tp — north_star's split of the headline qlinear over the ranks of one node (bench.py --gpus N / --mode tp): every exchange form a timed, verified leg."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+from .common import PEAK_HBM_GBS, PEAK_INT8_TOPS, emit_json, emit_marker, graph_of, test_hooks, traffic_for
+
+
+class _Watchdog:
+    """A collective that hangs cannot be cancelled from inside the process.  Every leg that drives the native exchange (a second RCCL communicator inside
+    libpq_rccl.so) therefore runs with this timer armed FOR THAT LEG ONLY (armed just before the leg's first native collective, cancelled when the leg's result is
+    recorded — ADVICE r4: the round-4 timer covered the whole rest of the benchmark): if it fires, rank 0 prints the best line the legs that DID finish and verify
+    support, with top-level "native_exchange": "hung" and the leg's name, and every rank leaves with status 0 (a fresh exit, no re-exec)."""
+
+    def __init__(self, rank, compose):
+        import threading
+        self._threading, self.rank, self.compose = threading, rank, compose
+        self.lock, self.done, self.timer, self.leg = threading.Lock(), False, None, None
+
+    def arm(self, leg, seconds):
+        self.disarm()
+        self.leg = leg
+        self.timer = self._threading.Timer(seconds, self._fire, args=(leg, seconds))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self, leg, seconds):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            line = None
+            try:
+                line = self.compose(hung_leg=leg, timeout=seconds)
+            except Exception as e:
+                print(f"[bench] rank {self.rank}: composing the line after a hang failed: {e}", file=sys.stderr)
+            print(f"[bench] rank {self.rank}: the native RCCL leg '{leg}' did not finish within {seconds:.0f} s — "
+                  + ("printing the best verified line of the legs that finished" if line else "no finished leg either"), file=sys.stderr)
+            if self.rank == 0 and line is not None:
+                emit_json(line)
+            sys.stderr.flush()
+            os._exit(0 if line is not None else 3)
+
+
+def run_tp(args, world, rank, dev, dist, cpu_fn=None):
+    """north_star's split of the headline qlinear over `world` ranks (one process per GPU): W column-sharded over the output channels, the activation
+    replicated (every rank runs K1 itself), ONE all-gather of the bf16 output shards per step.  The repo holds several forms of that exchange;
+    each is a LEG here: timed by the same protocol (W warm-up steps + warm-up by time, R blocks of exactly K steps between barrier + synchronize, max over ranks,
+    median block), replayed whole from a hipGraph where it can be captured, and VERIFIED — every rank compares the y it ends up holding, bit for bit, with the
+    unsharded qlinear it computes itself from the full weight.  The headline `value` is the fastest leg that finished AND verified; every leg is listed under
+    `legs`.  Legs:
+      torch_plain / torch_transposed   torch.distributed's own all-gather (the path every PyTorch job uses), issued eagerly behind the compute graph — measured
+                                       FIRST: they are the line a hung native collective falls back to
+      native_plain                     pq_allgather_cols_v: ncclAllGather into a stacked workspace + layout kernel
+      native_transposed                pq_qlinear_s8_t + pq_allgather_rows_t: transposed shards, ONE contiguous ncclAllGather, no layout pass (SURVEY.md §8(e) option 1)
+      native_overlap{2,4,8}            row blocks: each block's exchange (pq_allgather_cols_rows_async, the communicator's side stream) runs under the next block's
+                                       GEMM; pq_comm_join at the end of the step (SURVEY.md:303 "chunked along M and overlapped with K3")"""
+    import protoquant_amd as pq
+    from protoquant_amd import _lib as L
+    from protoquant_amd.sharded import shard_bounds, gather_columns
+    lib = L.lib()
+    hooks = test_hooks()
+    M, N, K = args.M, args.N, args.K
+    st = lambda: torch.cuda.current_stream().cuda_stream     # noqa: E731
+    med = lambda v: sorted(v)[len(v) // 2]                   # noqa: E731
+    K_steps, R, PG = max(1, args.steps), max(1, args.repeats), 20
+    lo, hi = shard_bounds(N, world, rank)
+    n_local = hi - lo
+    equal = N % world == 0
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_min(flag):
+        t = torch.tensor([1 if flag else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def all_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def ev_us(g, n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); b.synchronize()
+        return a.elapsed_time(b) * 1e3 / n
+
+    # ---- synthetic data, seeded on the CPU generator so every rank and every box agree.  Every rank holds the FULL weight as well: it is what
+    # the verification computes the unsharded qlinear from (per-channel quantisation is row-local: the rank's shard is a row block of the full codes).
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    gw = torch.Generator().manual_seed(4321)
+    qw = pq.quantize((torch.randn(N, K, generator=gw) * 0.02).to(torch.bfloat16).to(dev))
+    wq_full, ws_full = qw.int_data, qw.scale
+    wq, ws = wq_full[lo:hi].clone(), ws_full[lo:hi].clone()       # the rank's shard (own allocations: aligned bases for any split)
+    xq = torch.empty((M, K), dtype=torch.int8, device=dev)
+    xs = torch.empty((M,), dtype=torch.float32, device=dev)
+    y_loc = torch.empty((M, n_local), dtype=torch.bfloat16, device=dev)
+    yt_loc = torch.empty((n_local, M), dtype=torch.bfloat16, device=dev)
+    y_full = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    yt_full = torch.empty((N, M), dtype=torch.bfloat16, device=dev)
+
+    def wspace(nbytes):
+        return torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev), nbytes
+
+    def k1():
+        L.check(lib.pq_quant_rowwise(x.data_ptr(), 0, M, K, K, xq.data_ptr(), K, xs.data_ptr(), st()), "pq_quant_rowwise")
+
+    def gemm_rows(m0, m1, wsp, wb, w=None, wsc=None, out=None, ldo=None, n=None):
+        w = wq if w is None else w; wsc = ws if wsc is None else wsc
+        out = y_loc if out is None else out; n = n_local if n is None else n; ldo = n if ldo is None else ldo
+        L.check(lib.pq_qlinear_s8(xq.data_ptr() + m0 * K, K, xs.data_ptr() + 4 * m0, w.data_ptr(), K, wsc.data_ptr(), None,
+                                  out.data_ptr() + 2 * m0 * ldo, ldo, 0, m1 - m0, n, K, wsp.data_ptr() if wb else None, wb, st()), "pq_qlinear_s8")
+    wsp_l, wb_l = wspace(lib.pq_qlinear_workspace_bytes(M, n_local, K))
+    wsp_t, wb_t = wspace(lib.pq_qlinear_t_workspace_bytes(M, n_local, K))
+
+    def k3():
+        gemm_rows(0, M, wsp_l, wb_l)
+
+    def k3t():
+        L.check(lib.pq_qlinear_s8_t(xq.data_ptr(), K, xs.data_ptr(), wq.data_ptr(), K, ws.data_ptr(), None, yt_loc.data_ptr(), M, 0,
+                                    M, n_local, K, wsp_t.data_ptr() if wb_t else None, wb_t, st()), "pq_qlinear_s8_t")
+
+    # the unsharded qlinear on this rank: the bits every leg must reproduce
+    y_ref = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    wsp_f, wb_f = wspace(lib.pq_qlinear_workspace_bytes(M, N, K))
+    k1(); gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)
+    torch.cuda.synchronize()
+    y_ref_bits = y_ref.view(torch.int16)
+
+    # ---- per-kernel durations (no collective): the rank's shard GEMM (the `roofline` kernel), K1 cache-resident and HBM-fed, the compute step
+    gk1, gk3, gst = graph_of(k1, PG), graph_of(k3, PG), graph_of(lambda: (k1(), k3()), PG)
+    for g_ in (gk1, gk3, gst):
+        g_.replay()
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + min(args.warmup_seconds, 1.0)
+    while time.perf_counter() < t_end:
+        gst.replay(); torch.cuda.synchronize()
+    tk1, tk3, tst = [], [], []
+    for _ in range(max(R, 20)):
+        tst.append(ev_us(gst, PG)); tk3.append(ev_us(gk3, PG)); tk1.append(ev_us(gk1, PG))
+    t_gemm, t_k1_hot, t_stepc = med(tk3), med(tk1), med(tst)
+    n_rot = max(2, -(-600 * 2**20 // (3 * M * K)))
+    rot = [(torch.randn(M, K, device=dev).to(torch.bfloat16), torch.empty((M, K), dtype=torch.int8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
+           for _ in range(n_rot)]
+
+    def k1_rot():
+        for xr_, qr_, sr_ in rot:
+            L.check(lib.pq_quant_rowwise(xr_.data_ptr(), 0, M, K, K, qr_.data_ptr(), K, sr_.data_ptr(), st()), "pq_quant_rowwise")
+    g_rot = graph_of(k1_rot, 2)
+    g_rot.replay(); torch.cuda.synchronize()
+    t_k1 = med([ev_us(g_rot, 2 * n_rot) for _ in range(15)])
+    del rot, g_rot, gk1, gk3, gst
+    consistent = (t_gemm + t_k1_hot) <= 1.05 * t_stepc <= 1.05 * 1.05 * (t_gemm + t_k1)
+    if not consistent:      # several ranks share one host and one power envelope: a multi-GPU line is never lost to this check, it carries the flag
+        print(f"[bench] WARNING (rank {rank}): GEMM {t_gemm:.2f} us + K1 {t_k1_hot:.2f} (cache-resident) .. {t_k1:.2f} us (HBM) vs compute step {t_stepc:.2f} us", file=sys.stderr)
+
+    # ---- the legs
+    class Leg:
+        def __init__(self, name, exchange, compute, comm, result, clear, native, capturable, what, chunks=1):
+            self.name, self.exchange, self.compute, self.comm, self.result, self.clear = name, exchange, compute, comm, result, clear
+            self.native, self.capturable, self.what, self.chunks = native, capturable, what, chunks
+
+        def step(self):
+            self.compute(); self.comm()
+
+    def tg_plain():
+        y_full.copy_(gather_columns(y_loc, N))
+
+    def tg_t():
+        if equal:
+            dist.all_gather_into_tensor(yt_full.view(-1), yt_loc.view(-1))
+        else:
+            from protoquant_amd.sharded import gather_rows_t
+            yt_full.copy_(gather_rows_t(yt_loc, N))
+    clear_rows = lambda: (y_full.zero_(), y_loc.zero_())       # noqa: E731
+    clear_t = lambda: (yt_full.zero_(), yt_loc.zero_())        # noqa: E731
+    legs = [Leg("torch_plain", f"torch.distributed all_gather_into_tensor ({args.backend}) + layout pass", lambda: (k1(), k3()), tg_plain, lambda: y_full, clear_rows, False, False,
+                "K1 + shard GEMM from a hipGraph, the collective issued eagerly behind each step"),
+            Leg("torch_transposed", f"pq_qlinear_s8_t + torch.distributed all_gather_into_tensor ({args.backend}) straight into y^T[N, M], no layout pass", lambda: (k1(), k3t()), tg_t,
+                lambda: yt_full.t(), clear_t, False, False, "transposed shards: the gather is contiguous; y is the column-major view y^T.t() (same bits)")]
+    rg, native_state = None, "not_attempted"
+    want_native = args.backend == "nccl" and not args.torch_gather
+    results, order = {}, []
+    shared = {"native_state": native_state}
+
+    def leg_model(leg, t_comp):
+        """DESIGN.md §6's model of this leg for this G: the rank's MEASURED compute, the all-gather at the point-to-point link rate (every peer's shard arrives over its
+        own xGMI link, ~153 GB/s each, all links busy at once) and, for the row-major forms, the layout pass (reads + writes 2 M N bytes at ~5 TB/s)."""
+        XGMI_LINK_GBS, LAYOUT_TBS = 153.0, 5.0
+        shard_bytes = 2 * M * n_local
+        ag = shard_bytes / (XGMI_LINK_GBS * 1e3) if world > 1 else 2 * M * N / (LAYOUT_TBS * 1e6)     # world 1: a device-local copy
+        lay = 0.0 if "transposed" in leg.name else 2 * (2 * M * N) / (LAYOUT_TBS * 1e6)
+        C = leg.chunks
+        if C > 1:           # pipeline of C row blocks: the first block's GEMM and the last block's exchange are exposed, the rest runs at the slower of the two
+            c, e = (t_comp - t_k1_hot) / C, (ag + lay) / C
+            step = t_k1_hot + c + (C - 1) * max(c, e) + e
+        else:
+            step = t_comp + ag + lay
+        return {"compute_us": round(t_comp, 2), "allgather_us": round(ag, 2), "layout_pass_us": round(lay, 2), "step_us": round(step, 2),
+                "assumptions": f"per-rank shard {shard_bytes} B over one direct xGMI link per peer at {XGMI_LINK_GBS:.0f} GB/s, all {max(world - 1, 1)} links concurrently; "
+                               f"layout pass at {LAYOUT_TBS:.0f} TB/s; " + (f"{C} row blocks, exchange of block i under the GEMM of block i+1" if C > 1 else "no overlap of exchange and compute")
+                               + " (DESIGN.md §6)"}
+
+    def run_leg(leg):
+        """time + verify one leg; returns its record"""
+        rec = {"exchange": leg.exchange, "what": leg.what, "native": leg.native, "verified": False}
+        S, g_main, g_rem, in_graph = 1, None, None, False
+        leg.step(); torch.cuda.synchronize()                      # (allocates exchange workspaces outside any capture)
+        if leg.capturable and not args.no_graph:
+            try:
+                S = min(K_steps, 20)
+                g_main = graph_of(leg.step, S)
+                if K_steps % S:
+                    g_rem = graph_of(leg.step, K_steps % S)
+                in_graph = True
+            except Exception as e:
+                print(f"[bench] leg {leg.name}: capturing the exchange into the step graph failed ({e}); collective issued eagerly behind each step", file=sys.stderr)
+            in_graph = all_min(in_graph)                            # every rank must replay the same thing
+            if not in_graph:
+                g_main = g_rem = None
+        g_comp = None
+        if not in_graph:
+            S = 1
+            if not args.no_graph:
+                g_comp = graph_of(leg.compute, 1)
+
+        def run_steps(n):
+            if in_graph:
+                for _ in range(n // S):
+                    g_main.replay()
+                if n % S:
+                    (g_rem if (g_rem is not None and n % S == K_steps % S) else graph_of(leg.step, n % S)).replay()
+                return
+            for _ in range(n):
+                if g_comp is not None:
+                    g_comp.replay()
+                else:
+                    leg.compute()
+                leg.comm()
+        run_steps(args.warmup)
+        fence()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.warmup_seconds:
+            run_steps(K_steps)
+            torch.cuda.synchronize()
+        fence()
+        blocks, host_enq = [], []
+        for _ in range(R):
+            fence()
+            t0 = time.perf_counter()
+            run_steps(K_steps)
+            host_enq.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            blocks.append(all_max(time.perf_counter() - t0))
+        blocks.sort()
+        dt = blocks[len(blocks) // 2]
+        # verification: outputs cleared, exactly the timed step once more, then every rank compares what it holds with its own unsharded qlinear
+        leg.clear(); torch.cuda.synchronize()
+        run_steps(S if in_graph else 1)
+        torch.cuda.synchronize()
+        got = leg.result()
+        same = tuple(got.shape) == (M, N) and bool(torch.equal(got.contiguous().view(torch.int16), y_ref_bits))
+        rec["verified"] = all_min(same)
+        if not same:
+            print(f"[bench] rank {rank}: leg {leg.name} does NOT reproduce the unsharded qlinear", file=sys.stderr)
+        # the leg's compute alone (K1 + its GEMM launches) and its exchange alone, gap-free from their own graphs where capturable
+        t_comp = t_exch = None
+        try:
+            gc_ = graph_of(leg.compute, PG)
+            gc_.replay(); torch.cuda.synchronize()
+            t_comp = med([ev_us(gc_, PG) for _ in range(9)])
+            del gc_
+            fence()
+            if in_graph:
+                ge_ = graph_of(leg.comm, PG)
+                ge_.replay(); fence()
+                v = med([ev_us(ge_, PG) for _ in range(9)])
+                del ge_
+            else:
+                def ex_eager():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(PG):
+                        leg.comm()
+                    b.record(); b.synchronize()
+                    return a.elapsed_time(b) * 1e3 / PG
+                ex_eager(); fence()
+                v = med([ex_eager() for _ in range(5)])
+            t_exch = all_max(v)
+            fence()
+        except Exception as e:
+            print(f"[bench] leg {leg.name}: compute / exchange-only timing failed: {e}", file=sys.stderr)
+        host_us = med(host_enq) / K_steps * 1e6
+        step_us = dt / K_steps * 1e6
+        rec.update({"value": round(2.0 * M * N * K * K_steps / dt / 1e12, 2), "unit": "TOPS", "ms_per_step": round(dt / K_steps * 1e3, 5),
+                    "ms_per_step_min": round(blocks[0] / K_steps * 1e3, 5), "ms_per_step_max": round(blocks[-1] / K_steps * 1e3, 5),
+                    "collective_in_graph": in_graph,
+                    "launch": (f"hipgraph x{S} steps/replay, exchange captured in the graph" if in_graph else
+                               ("hipgraph x1 step/replay (compute), collective eager behind each step" if g_comp is not None else "eager")),
+                    "host_enqueue_us_per_step": round(host_us, 2), "host_bound": bool((not in_graph) and host_us > 0.9 * step_us),
+                    "compute_us": round(t_comp, 2) if t_comp is not None else None, "exchange_us": round(t_exch, 2) if t_exch is not None else None})
+        if t_comp is not None:
+            rec["modelled"] = leg_model(leg, t_comp)
+            rec["measured_minus_modelled_us"] = round(step_us - rec["modelled"]["step_us"], 2)
+        return rec
+
+    def compose(hung_leg=None, timeout=None):
+        """the ONE JSON line from whatever has finished so far (called at the end, or by the watchdog)"""
+        done = {n: results[n] for n in order if n in results}
+        ok = [n for n in done if done[n]["verified"] and "value" in done[n]]
+        timed = [n for n in done if "ms_per_step" in done[n]]
+        if not timed:
+            return None
+        head = min(ok, key=lambda n: done[n]["ms_per_step"]) if ok else None
+        h = done[head] if head else done[timed[0]]          # (no verified leg: the line carries value 0 and verified = false)
+        variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
+        kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
+                 "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
+        if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
+            kname += " split-K + splitk_reduce_epilogue"
+        gemm_ops, gemm_bytes, k1_bytes = 2.0 * M * n_local * K, M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local), 3 * M * K + 4 * M
+        out = {
+            "metric": "int8 TOPS for qlinear M=4096 N=K=4096 (row-quant + s8 MFMA GEMM + fused dequant); HBM GB/s of the quant pass in quant_pass",
+            "value": h["value"] if head else 0.0, "unit": "TOPS", "n_gpus": world, "steps": K_steps, "warmup": args.warmup,
+            "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s8", "data": "synthetic",
+            "config": {"workload": f"qlinear M={M} N={N} K={K} bf16-in/int8-compute/bf16-out (BASELINE configs[1])",
+                       "parallelism": f"tp{world}: W column-sharded ({n_local} of {N} output channels per rank), replicated activation, RCCL all-gather of the bf16 shards after dequant",
+                       "headline_leg": head, "exchange": h["exchange"], "launch": h["launch"], "collective_in_graph": h["collective_in_graph"],
+                       "rccl_ranks": shared.get("rccl_ranks", dist.get_world_size()), "native": bool(h["native"]),
+                       "repeats": R, "timed": f"per leg: median of {R} blocks of exactly {K_steps} steps (barrier + synchronize around each block, max over ranks); headline = the fastest "
+                                              "leg that finished AND reproduced the unsharded qlinear bit for bit on every rank",
+                       "warmup_seconds": args.warmup_seconds, "gemm_variant": variant},
+            "verified": bool(head is not None), "ms_per_step_min": h["ms_per_step_min"], "ms_per_step_max": h["ms_per_step_max"],
+            "legs": done, "native_exchange": "hung" if hung_leg else shared["native_state"],
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(gemm_ops / t_gemm / 1e6, 1), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
+                         "frac": round(gemm_ops / t_gemm / 1e6 / PEAK_INT8_TOPS, 4), "avg_kernel_us": round(t_gemm, 2), "avg_kernel_us_min": round(min(tk3), 2),
+                         "how": f"the rank's shard GEMM {M}x{n_local}x{K}: median of {len(tk3)} hipGraph replays of {PG} back-to-back launches, HIP events on the launch stream",
+                         "traffic": None, "algorithmic_bytes": gemm_bytes},
+            "quant_pass": {"bound": "hbm", "kernel": "quant_rowwise_vec (K1)", "achieved": round(k1_bytes / t_k1 / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(k1_bytes / t_k1 / 1e3 / PEAK_HBM_GBS, 4), "avg_kernel_us": round(t_k1, 2), "algorithmic_bytes": k1_bytes,
+                           "how": f"gap-free hipGraph replays rotating over {n_rot} distinct input/output pairs: every launch is HBM-fed",
+                           "in_step_us": round(t_stepc - t_gemm, 2), "cache_resident_replay_us": round(t_k1_hot, 2)},
+            "compute_step_us": round(t_stepc, 2), "timings_consistent": bool(consistent),
+            "host_enqueue_us_per_step": h["host_enqueue_us_per_step"], "host_bound": h["host_bound"],
+            "compute_us": h["compute_us"], "exchange_us": h["exchange_us"], "exchange_bytes_received_per_rank": 2 * M * (N - n_local),
+            "cpu_baseline": shared.get("cpu_baseline"),
+        }
+        if "modelled" in h:
+            out["modelled"] = h["modelled"]
+            out["config"]["modelled_step_us"] = h["modelled"]["step_us"]
+            out["measured_minus_modelled_us"] = h["measured_minus_modelled_us"]
+        if "torch_plain" in done and "ms_per_step" in done["torch_plain"]:
+            out["torch_distributed_exchange_ms_per_step"] = done["torch_plain"]["ms_per_step"]
+        if "dp" in shared:
+            out["dp"] = shared["dp"]
+        if hung_leg:
+            out["hung_leg"] = hung_leg
+            out["fallback"] = (f"the native exchange leg '{hung_leg}' (libpq_rccl.so) did not finish within {timeout:.0f} s: the line is the fastest verified leg among those that "
+                               "finished before it")
+        # (the rank's shard GEMM: PMC passes per shard width, tools/pmc_traffic_shards.sh)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic_for((M, n_local, K))
+        return out
+
+    dog = _Watchdog(rank, compose)
+    # the torch.distributed legs first: the net under everything that follows
+    for leg in legs:
+        order.append(leg.name)
+        try:
+            results[leg.name] = run_leg(leg)
+        except Exception as e:
+            print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
+            results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": False}
+
+    emit_marker("safe")                                  # (to the rank's supervisor: the torch.distributed legs are in)
+    if rank == 0:
+        emit_json(compose(), final=False)
+    # The host baseline NOW — between the safe legs and the native bootstrap: every line printed from here on, also the provisional ones a supervisor
+    # prints after a crash and the watchdog's, carries `cpu_baseline`.  Rank 0 works on the host (~20 s), the other ranks wait at the barrier below; no watchdog is armed,
+    # no native collective has been touched, the GPUs idle.
+    if rank == 0 and cpu_fn is not None and not args.no_cpu_baseline:
+        try:
+            shared["cpu_baseline"] = cpu_fn(M, N, K, budget_s=20.0)
+            emit_json(compose(), final=False)
+        except Exception as e:
+            print(f"[bench] cpu baseline failed: {e}", file=sys.stderr)
+    fence()
+    if want_native and hooks.get("native-crash"):
+        import signal
+        sys.stderr.flush()
+        os.kill(os.getpid(), signal.SIGSEGV)
+    if want_native:
+        def boot():
+            from protoquant_amd.sharded import RcclColumnGather
+            return RcclColumnGather()
+        dog.arm("communicator bootstrap", args.native_timeout)
+        if hooks.get("native-hang"):
+            while True:
+                time.sleep(1.0)
+        try:
+            rg = boot()
+        except Exception as e:
+            print(f"[bench] native RCCL exchange unavailable ({e})", file=sys.stderr)
+            rg = None
+        if not all_min(rg is not None):          # every rank must take the same path
+            rg = None
+        dog.disarm()
+        shared["native_state"] = "ok" if rg is not None else "unavailable"
+    if rg is not None:
+        shared["rccl_ranks"] = rg.comm_ranks()
+        nat = [Leg("native_plain", "libpq_rccl.so pq_allgather_cols_v (ncclAllGather + layout kernel)", lambda: (k1(), k3()), lambda: rg.gather_into(y_loc, y_full, N),
+                   lambda: y_full, clear_rows, True, True, "the whole step (K1, shard GEMM, ncclAllGather, layout kernel) in one hipGraph"),
+               Leg("native_transposed", "libpq_rccl.so pq_qlinear_s8_t + pq_allgather_rows_t (one contiguous ncclAllGather, no layout kernel)", lambda: (k1(), k3t()),
+                   lambda: rg.gather_t(yt_loc, N, out=yt_full), lambda: yt_full.t(), clear_t, True, True,
+                   "transposed shards gathered in place; y is the column-major view y^T.t() (same bits)")]
+        for C in (2, 4, 8):
+            if M // C < 256:
+                continue
+            bounds = [shard_bounds(M, C, c) for c in range(C)]
+            wsp_c, wb_c = wspace(max(lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K) for m0, m1 in bounds))
+
+            def comp_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
+                k1()
+                for m0, m1 in bounds:
+                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
+
+            def comm_c(bounds=bounds):
+                for m0, m1 in bounds:
+                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
+                rg.join(dev)
+
+            def step_c(bounds=bounds, wsp_c=wsp_c, wb_c=wb_c):
+                k1()
+                for m0, m1 in bounds:
+                    gemm_rows(m0, m1, wsp_c, min(wb_c, lib.pq_qlinear_workspace_bytes(m1 - m0, n_local, K)))
+                    rg.gather_rows_async(y_loc, y_full, m0, m1, N)
+                rg.join(dev)
+            lg = Leg(f"native_overlap{C}", f"libpq_rccl.so pq_allgather_cols_rows_async x{C} row blocks on the communicator's side stream + pq_comm_join", comp_c, comm_c,
+                     lambda: y_full, clear_rows, True, True, f"{C} row blocks: the exchange of block i runs under the GEMM of block i+1; the whole step in one hipGraph", chunks=C)
+            lg.step = step_c
+            nat.append(lg)
+        for leg in nat:
+            order.append(leg.name)
+            dog.arm(leg.name, args.native_timeout)
+            if hooks.get("leg-hang") == leg.name:
+                while True:
+                    time.sleep(1.0)
+            try:
+                results[leg.name] = run_leg(leg)
+            except Exception as e:
+                print(f"[bench] leg {leg.name} failed: {e}", file=sys.stderr)
+                results[leg.name] = {"exchange": leg.exchange, "verified": False, "error": str(e)[:300], "native": True}
+            ok_everywhere = all_min("error" not in results[leg.name])   # (still under the leg's watchdog: a rank that raised is out of step with the others' collectives)
+            dog.disarm()
+            if rank == 0:
+                with dog.lock:
+                    if not dog.done:
+                        emit_json(compose(), final=False)                # provisional: what the supervisor prints if a later leg kills this process
+            if not ok_everywhere:                                       # stop trying native legs
+                shared["native_state"] = "failed"
+                break
+
+    if not args.no_dp_leg:
+        # extra key: the same ranks as independent replicas over tokens (weak scaling, replicated weights, no collective), short
+        try:
+            gd = graph_of(lambda: (k1(), gemm_rows(0, M, wsp_f, wb_f, wq_full, ws_full, y_ref, N, N)), PG)
+            for _ in range(10):
+                gd.replay()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(25):
+                gd.replay()
+            torch.cuda.synchronize()
+            d = all_max(time.perf_counter() - t0)
+            shared["dp"] = {"value": round(2.0 * M * N * K * world * 25 * PG / d / 1e12, 2), "unit": "TOPS", "scaling": "weak",
+                            "parallelism": f"dp{world} over tokens, replicated int8 weights, no collective"}
+        except Exception as e:
+            print(f"[bench] dp leg failed: {e}", file=sys.stderr)
+    with dog.lock:
+        if dog.done:
+            return
+        dog.done = True
+        dog.disarm()
+        if rank == 0:
+            emit_json(compose())
+    if rg is not None:
+        try:
+            rg.close()
+        except Exception:
+            pass
+    dist.barrier()
+    dist.destroy_process_group()
+

@@ -106,3 +106,6 @@ def test_plain_invocation_reports_a_failed_launch():
 def test_optional_workloads_run(args, unit):
     d = _run(*args)
     assert d["unit"] == unit and d["value"] > 0 and "roofline" in d and "workload" in d["config"]
+    # round 6: every workload line carries the host baseline of THAT workload (one layer x L for the models) in the line's own unit
+    c = d["cpu_baseline"]
+    assert c is not None and c["kind"] == "port" and c["unit"] == unit and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and d["value"] > c["value"]

@@ -91,12 +91,13 @@ def test_bench_tp_step_is_one_graph_world1():
     assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True and line["cpu_baseline"] is None
 
 
-def _bench_tp(extra, port):
-    env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench_tp(extra, port, hooks="", cpu_baseline=False, env_extra=None):
+    """bench.py --mode tp at world 1; `hooks` = PQ_BENCH_TEST_HOOKS (the test hooks live in the environment, not on bench.py's command line: round 6)"""
+    env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", PQ_BENCH_TEST_HOOKS=hooks, **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3", "--warmup-seconds", "0.3",
-                        "--no-cpu-baseline", "--no-dp-leg", *extra], env=env, capture_output=True, text=True, timeout=600)
+                        *([] if cpu_baseline else ["--no-cpu-baseline"]), "--no-dp-leg", *extra], env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, lines
 
@@ -105,7 +106,7 @@ def test_bench_tp_watchdog_prints_the_best_finished_leg_when_a_native_leg_hangs(
     """A multi-GPU run must never be lost to a hung collective: the torch.distributed legs are measured (and verified) before the native exchange (a second RCCL
     communicator) is touched, and every native leg runs under its own watchdog; when one does not finish in time, rank 0 prints the fastest VERIFIED leg among
     those that finished, marked "native_exchange": "hung", and the rank exits 0.  Here the hang is simulated (the native phase never returns)."""
-    r, lines = _bench_tp(["--simulate-native-hang", "--native-timeout", "8"], "29565")
+    r, lines = _bench_tp(["--native-timeout", "8"], "29565", hooks="native-hang")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
@@ -130,7 +131,7 @@ def test_bench_tp_line_says_native_ok_when_every_leg_finishes():
 def test_bench_tp_watchdog_keeps_the_native_legs_that_finished():
     """a hang in the THIRD native leg: the line carries the two native legs that finished (verified, captured in the graph) beside the torch.distributed ones, the
     headline is the fastest of them all, and the hung leg is named."""
-    r, lines = _bench_tp(["--simulate-leg-hang", "native_overlap2", "--native-timeout", "10"], "29567")
+    r, lines = _bench_tp(["--native-timeout", "10"], "29567", hooks="leg-hang=native_overlap2")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
@@ -145,7 +146,7 @@ def test_bench_tp_supervisor_keeps_the_safe_line_when_the_worker_dies():
     collective — a segfault, a GPU memory fault — cannot be caught in the process it kills, so the worker reports every line it could print so far through a pipe
     and the supervisor prints the last one.  Here at one rank (--supervise), the worker killing itself with SIGSEGV when it reaches the native exchange: the line of
     the verified torch.distributed legs comes out, marked "native_exchange": "crashed", and the exit status is 0."""
-    r, lines = _bench_tp(["--supervise", "--simulate-native-crash"], "29568")
+    r, lines = _bench_tp([], "29568", hooks="supervise,native-crash")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
@@ -153,8 +154,32 @@ def test_bench_tp_supervisor_keeps_the_safe_line_when_the_worker_dies():
     assert line["verified"] is True and line["value"] > 0 and line["config"]["headline_leg"] in line["legs"] and "worker ended with status" in r.stderr
 
 
+def test_bench_tp_survivor_line_is_complete():
+    """the line a supervisor prints after its worker died in the native exchange carries ALL of `legs`, `verified`, `cpu_baseline` and `roofline` —
+    rank 0 computes the host baseline between the safe legs and the native bootstrap, so every provisional line holds it.  With PQ_BENCH_STRICT_EXIT=1 the same crash
+    ends with the distinct status 17 (CI), line printed all the same."""
+    r, lines = _bench_tp([], "29570", hooks="supervise,native-crash", cpu_baseline=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["native_exchange"] == "crashed" and line["verified"] is True and set(line["legs"]) == {"torch_plain", "torch_transposed"}
+    c, rf = line["cpu_baseline"], line["roofline"]
+    assert c is not None and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert rf["bound"] == "mfma" and rf["frac"] > 0.2 and rf["traffic"] is not None and rf["traffic"] > 6e7
+    r, lines = _bench_tp([], "29571", hooks="supervise,native-crash", env_extra={"PQ_BENCH_STRICT_EXIT": "1"})
+    assert r.returncode == 17 and len(lines) == 1 and json.loads(lines[0])["native_exchange"] == "crashed", (r.returncode, r.stderr[-2000:])
+
+
+def test_bench_tp_watchdog_line_carries_the_cpu_baseline():
+    """... and so does the line the in-process watchdog prints when the native bootstrap hangs"""
+    r, lines = _bench_tp(["--native-timeout", "8"], "29572", hooks="native-hang", cpu_baseline=True)
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line["native_exchange"] == "hung" and line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0 and line["verified"] is True
+
+
 def test_bench_tp_supervisor_relays_the_final_line():
-    r, lines = _bench_tp(["--supervise"], "29569")
+    r, lines = _bench_tp([], "29569", hooks="supervise")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
