@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--workload", choices=["qlinear", "mlp", "llama8b", "llama8b-linears", "llama70b-shard"], default="qlinear",
                     help="qlinear = BASELINE configs[1] (default, the headline); mlp = configs[2]: Llama MLP block 4096->11008->4096, seq 2048; llama8b = configs[3]: every linear of Llama-3-8B at prefill seq 4096 (linears only)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="llama70b-shard workload: the main composition only (no pairing / int8-exchange / per-shape legs): counter passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-context", action="store_true", help="skip the stock torch-ROCm legs on this GPU (torch._int_mm pipeline, bf16 linear)")
     ap.add_argument("--tokens", type=int, default=4096, help="llama8b workload: tokens per pass (4096 = BASELINE configs[3] prefill; <= 512 = decode-like, replayed from a hipGraph)")

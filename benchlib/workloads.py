@@ -351,6 +351,8 @@ def run_llama70b_shard(args, oracle=None):
     # per rank, GEMM shapes 4096 x 8192 x 1024 and 4096 x 8192 x 3584 instead of the 1024-wide column shards.
     pairing = None
     try:
+        if args.no_extras:
+            raise RuntimeError("--no-extras")
         rl = [(mkq(H, H // G), mkq(H, I // G)) for _ in range(NL)]
         x_a = torch.randn(M, H // G, device=dev).to(torch.bfloat16)          # stands for this rank's heads of the attention output
 
@@ -380,13 +382,16 @@ def run_llama70b_shard(args, oracle=None):
                    "model": "per layer 2 x (reduce-scatter of f32 partials [M,H] + all-gather of bf16 row blocks), 7 xGMI links x 153 GB/s; NOT measured"}
         del rl
     except Exception as e:      # an extra figure must never lose the main line
-        print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
+        if not args.no_extras:
+            print(f"[bench] row-sharded pairing leg failed: {e}", file=sys.stderr)
     # Extra key — the INT8-CODE EXCHANGE between gate/up and down (ColumnShardedGatedMLP: everything stays column-sharded, as north_star asks): the rank computes
     # silu*mul on ITS 3584 intermediate channels only — row amax of the local block, [all-reduce(max) of 4096 32-bit patterns: not run on one GPU], encode against the
     # global amax — and the down shard's GEMM walks the all-gathered int8 blocks [8, 4096, 3584] in place.  Against the plain composition above, the re-quantisation of
     # the gathered 4096 x 28672 activation on every rank (and the gather of bf16 gate AND up: 4 bytes per intermediate element instead of 1) is gone.
     int8x = None
     try:
+        if args.no_extras:
+            raise RuntimeError("--no-extras")
         from protoquant_amd.qtensor import quantize_with_amax, rowamax, silu_mul_quantize_with_amax, silu_mul_rowamax
         ig = I // G
         stacked = torch.randint(-127, 128, (G, M, ig), device=dev, dtype=torch.int8)          # stands for the all-gathered code blocks
@@ -431,12 +436,15 @@ def run_llama70b_shard(args, oracle=None):
                  "modelled_gate_up_to_down_hop_us": {"bf16_gather_of_gate_and_up_plus_layout": round(hop_bf16 * 1e6, 1), "int8_code_exchange": round(hop_int8 * 1e6, 1),
                                                      "model": "bytes over one direct xGMI link per peer at 153 GB/s, all 7 links at once; layout passes at 5 TB/s; NOT measured"}}
     except Exception as e:      # an extra figure must never lose the main line
-        print(f"[bench] int8-code exchange leg failed: {e}", file=sys.stderr)
+        if not args.no_extras:
+            print(f"[bench] int8-code exchange leg failed: {e}", file=sys.stderr)
     # ---- where the step goes: every distinct kernel of a layer by itself, gap-free from its own hipGraph (all NL weight sets in turn: HBM-fed like the step),
     # with its share of the layer and — for the GEMMs —
     # its fraction of the int8 peak: the per-shape account of the distance to 0.50
     per_shape = None
     try:
+        if args.no_extras:
+            raise RuntimeError("--no-extras")
         def ev_graph(fn, n=8):
             g = graph_of(fn, n)
             g.replay(); torch.cuda.synchronize()
@@ -507,7 +515,8 @@ def run_llama70b_shard(args, oracle=None):
                 ex.append(d)
             int8x["kernels"] = ex
     except Exception as e:
-        print(f"[bench] per-shape leg failed: {e}", file=sys.stderr)
+        if not args.no_extras:
+            print(f"[bench] per-shape leg failed: {e}", file=sys.stderr)
     # exchange model: every linear's bf16 output is all-gathered after dequant; a rank receives (G-1)/G of it over 7 xGMI links x ~153 GB/s
     gathered = L * 2.0 * M * (H + 2 * KVD + H + 2 * I + H) + 2.0 * M * V
     t_gather = gathered * (G - 1) / G / (7 * 153e9)
