@@ -85,7 +85,13 @@ __device__ __forceinline__ float load_bias(const void* bias, int64_t n) {
 // The block is staged in passes of QT_PASS row tiles x PT_PASS column tiles that fit the wave's region
 // (QT_PASS * 16 rows of PT_PASS * 16 * sizeof(out) bytes); LDS operations of one wave execute in order, so a pass may
 // overwrite the region as soon as its reads are issued, and only the write -> read turn waits (lgkmcnt(0)).
-// Swizzle: 16-byte chunk c of staged row r sits at chunk c ^ (r & KM): conflict-free ds_read_b128, 2-way ds_write_b64.
+// Swizzle: 16-byte chunk c of staged row r sits at chunk c ^ (r & KM): conflict-free ds_read_b128.
+// 16-bit outputs (ds_write_b64: four groups of 16 contiguous lanes — the 16 rows of one tile at one q — on 32 banks, MI355X_MICROARCH.md section LDS): with the chunk key alone
+// rows r and r + 8 of a 128- or 256-byte staged row meet on one bank pair — the 2-way conflict rounds 1-5 documented here and round 5's PMC pass counted (2^18 extra LDS cycles
+// per 4096^3 launch = 4 per write: profiles/r06_lds_bank_conflicts.txt).  Round 6 (HSWZ): the key is 3 bits (r & 7) and the two 8-byte HALVES of a chunk trade places in rows
+// with bit 3 set; the reader's row is it * RPI + lrow with lrow < RPI <= 8, so bit 3 is a compile-time property of the read and the halves are put back by naming the
+// registers the other way round: no instruction added, SQ_LDS_BANK_CONFLICT = 0.  (64-byte staged rows — the 64 x 64 ring tile — keep the old form: there bit 3 of the row
+// depends on the lane.)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // BIAS: 0 none, 1 along columns (n = 16 pt + 4 q + r), 2 along rows (m = 16 qt + c; EPI_BIAS_ROWS).  SWAP: EPI_COL_FIRST.
@@ -96,13 +102,14 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
     constexpr int OB = (int)sizeof(O);
     constexpr int RBY = PT_PASS * 16 * OB;                // staged row bytes: 64 (two half-precision column tiles: the 64 x 64 ring tile), 128, 256 or 512
     constexpr int CPR = RBY / 16;                         // 16-byte chunks per staged row
-    constexpr int KM = (CPR < 16 ? CPR : 16) - 1;         // swizzle key mask
+    constexpr bool HSWZ = (OB == 2) && RBY >= 128;        // 16-bit outputs: half-swap swizzle (above)
+    constexpr int KM = HSWZ ? 7 : ((CPR < 16 ? CPR : 16) - 1);         // swizzle key mask
     constexpr int RPI = 64 / CPR;                         // rows per ds_read_b128 / global store instruction: 8, 4 or 2
     constexpr int CSH = (OB == 2) ? 1 : 2;                // chunk of column tile p (inside a pass) = (p << CSH) | b
     static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && (RBY == 64 || RBY == 128 || RBY == 256 || RBY == 512), "epilogue pass shape");
     const int dcol = lane & 15, q = lane >> 4;
     const int b = (OB == 2) ? (q >> 1) : q;
-    const uint32_t low = (OB == 2) ? (uint32_t)(q & 1) * 8u : 0u;
+    const uint32_t low = (OB == 2) ? (uint32_t)((q & 1) ^ (HSWZ ? ((dcol >> 3) & 1) : 0)) * 8u : 0u;
     const uint32_t k2 = (uint32_t)(b ^ (dcol & KM));
     const uint32_t wbase = sw_off + (uint32_t)dcol * RBY + low;
     // hoisted per column tile: scales (and bias) of n = 16 pt + 4 q .. + 3
@@ -172,7 +179,11 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
 #pragma unroll
             for (int it = 0; it < QT_PASS * 16 / RPI; ++it) {
                 const int r = it * RPI + lrow;                                  // staged row of this lane
-                const v4u v = *reinterpret_cast<const v4u*>(smem + rbase + it * RPI * RBY + (((uint32_t)(ch ^ (r & KM))) << 4));
+                v4u v = *reinterpret_cast<const v4u*>(smem + rbase + it * RPI * RBY + (((uint32_t)(ch ^ (r & KM))) << 4));
+                if constexpr (HSWZ) {
+                    static_assert(RPI <= 8, "bit 3 of the staged row must not depend on the lane");
+                    if ((it * RPI) & 8) v = v4u{v[2], v[3], v[0], v[1]};         // (compile-time: `it` is unrolled)
+                }
                 uint8_t* rowp = y_blk + (int64_t)(qp * QT_PASS * 16 + it * RPI) * ldy_bytes + pp * RBY;   // wave-uniform
                 store_wt_b128(rowp + vlane, v);                                  // write-through (pq_common.h)
             }

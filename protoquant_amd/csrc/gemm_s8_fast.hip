@@ -1043,7 +1043,10 @@ bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb,
         int64_t lda_ = lda, ldb_ = ldb;
         EpiArgs epi_ = epi;
         unsigned long long* ws_ = ws;
-        void* args[] = {(void*)&A, (void*)&lda_, (void*)&B, (void*)&ldb_, (void*)&epi_, (void*)&M_, (void*)&N_, (void*)&K_, (void*)&tm_, (void*)&tn_, (void*)&zero, (void*)&ws_, (void*)&ks_};
+        int64_t no_stride = 0;
+        int no_tps = 0;          // (every parameter of the kernel: the trailing K-slab pair too — round 6)
+        void* args[] = {(void*)&A, (void*)&lda_, (void*)&B, (void*)&ldb_, (void*)&epi_, (void*)&M_, (void*)&N_, (void*)&K_, (void*)&tm_, (void*)&tn_, (void*)&zero, (void*)&ws_, (void*)&ks_,
+                        (void*)&no_stride, (void*)&no_tps};
         const void* fn = kslices == 2 ? reinterpret_cast<const void*>(&gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 2>)
                                       : reinterpret_cast<const void*>(&gemm_s8_sp256<OUT, 0, 256, 256, false, true, 1, 4, 4>);
         if (hipLaunchCooperativeKernel(fn, grid, block, args, 0, st) == hipSuccess) return true;
