@@ -100,13 +100,15 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
                                                  uint8_t* smem, uint32_t sw_off, uint8_t* y_blk, int64_t ldy_bytes, int lane) {
     using O = typename OutElem<OUT>::type;
     constexpr int OB = (int)sizeof(O);
-    constexpr int RBY = PT_PASS * 16 * OB;                // staged row bytes: 64 (two half-precision column tiles: the 64 x 64 ring tile), 128, 256 or 512
-    constexpr int CPR = RBY / 16;                         // 16-byte chunks per staged row
+    constexpr int RBU = PT_PASS * 16 * OB;                // bytes of a staged row that are USED: 64 (two half-precision column tiles: the 64 x 64 ring tile), 128, 160 (five: the 128 x 160 ring tile), 256, 320 or 512
+    constexpr int RBY = RBU <= 64 ? 64 : RBU <= 128 ? 128 : RBU <= 256 ? 256 : 512;      // ... and its stride in the staging region: the next power of two (round 6; the swizzle wants one)
+    constexpr int CPR = RBY / 16;                         // 16-byte chunks per staged row (stride)
+    constexpr int CPU = RBU / 16;                         // ... of which are used
     constexpr bool HSWZ = (OB == 2) && RBY >= 128;        // 16-bit outputs: half-swap swizzle (above)
     constexpr int KM = HSWZ ? 7 : ((CPR < 16 ? CPR : 16) - 1);         // swizzle key mask
     constexpr int RPI = 64 / CPR;                         // rows per ds_read_b128 / global store instruction: 8, 4 or 2
     constexpr int CSH = (OB == 2) ? 1 : 2;                // chunk of column tile p (inside a pass) = (p << CSH) | b
-    static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && (RBY == 64 || RBY == 128 || RBY == 256 || RBY == 512), "epilogue pass shape");
+    static_assert(NQT % QT_PASS == 0 && NPT % PT_PASS == 0 && RBU <= 512 && RBU % 16 == 0, "epilogue pass shape");
     const int dcol = lane & 15, q = lane >> 4;
     const int b = (OB == 2) ? (q >> 1) : q;
     const uint32_t low = (OB == 2) ? (uint32_t)((q & 1) ^ (HSWZ ? ((dcol >> 3) & 1) : 0)) * 8u : 0u;
@@ -179,12 +181,13 @@ __device__ __forceinline__ void epi_staged_block(AccFn&& acc_of, AsFn&& a_scale_
 #pragma unroll
             for (int it = 0; it < QT_PASS * 16 / RPI; ++it) {
                 const int r = it * RPI + lrow;                                  // staged row of this lane
+                if (CPU < CPR && ch >= CPU) continue;                            // (a padded stride: the lanes of the unused chunks sit the store out)
                 v4u v = *reinterpret_cast<const v4u*>(smem + rbase + it * RPI * RBY + (((uint32_t)(ch ^ (r & KM))) << 4));
                 if constexpr (HSWZ) {
                     static_assert(RPI <= 8, "bit 3 of the staged row must not depend on the lane");
                     if ((it * RPI) & 8) v = v4u{v[2], v[3], v[0], v[1]};         // (compile-time: `it` is unrolled)
                 }
-                uint8_t* rowp = y_blk + (int64_t)(qp * QT_PASS * 16 + it * RPI) * ldy_bytes + pp * RBY;   // wave-uniform
+                uint8_t* rowp = y_blk + (int64_t)(qp * QT_PASS * 16 + it * RPI) * ldy_bytes + pp * RBU;   // wave-uniform
                 store_wt_b128(rowp + vlane, v);                                  // write-through (pq_common.h)
             }
         }

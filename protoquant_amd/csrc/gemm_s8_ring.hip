@@ -196,10 +196,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s8_ringt(const int8_t* __restrict
         // staging: this wave's quarter of the first K-tile of the ring slot BEHIND the last one: no slot NS exists, so no DMA targets it, its previous
         // tenant (slot NS - NB) was read out long ago, and the last tile's prefetch of "tile NT" reads values nobody uses
         const uint32_t sw_off = (uint32_t)((NS % NB) * SLOT + w * (BUF / 4));
-        constexpr int PT_PASS = (NPI * 16 * OB > 256) ? NPI / 2 : NPI;
-        constexpr int QT_MAX = (BUF / 4) / (16 * PT_PASS * 16 * OB);
+        constexpr int PT_PASS = (NPI * 16 * OB > 256 && NPI % 2 == 0) ? NPI / 2 : NPI;       // (five column tiles — the 128 x 160 tile — stage in one pass of 160 / 320 used bytes per row)
+        constexpr int RSTRIDE = PT_PASS * 16 * OB <= 64 ? 64 : PT_PASS * 16 * OB <= 128 ? 128 : PT_PASS * 16 * OB <= 256 ? 256 : 512;      // gemm_epilogue.h: RBY
+        constexpr int QT_MAX = (BUF / 4) / (16 * RSTRIDE);
         constexpr int QT_PASS = QT_MAX >= NQJ ? NQJ : 1;
-        static_assert(QT_PASS >= 1 && QT_PASS * 16 * PT_PASS * 16 * OB <= BUF / 4, "epilogue staging region");
+        static_assert(QT_PASS >= 1 && QT_PASS * 16 * RSTRIDE <= BUF / 4, "epilogue staging region");
         auto acc_of = [&](int pt, int qt) -> const v4i& { return acc[pt][qt]; };
         auto as_of = [&](int qt) { return epi.a_scale[wm0 + qt * 16 + dcol]; };
         auto bs_of = [&](int pt) { return *reinterpret_cast<const v4f*>(epi.b_scale + wn0 + pt * 16 + drow4); };
@@ -250,7 +251,8 @@ static void rot_plan(int tiles_m, int tn, int* ct, int* rot_div) {
     *rot_div = force == 1 ? 0 : tiles_m;
 }
 
-// tile: 0 = 64(m) x 128(n), 3 slots of 2 K-tiles (144 KiB); 1 = 64 x 64, 4 slots of 2 K-tiles (128 KiB)
+// tile: 0 = 64(m) x 128(n), 3 slots of 2 K-tiles (144 KiB); 1 = 64 x 64, 4 slots of 2 K-tiles (128 KiB); 2 (round 6) = 128(m) x 160(n), 4 slots of 1 K-tile (144 KiB): the
+// tile that turns a 1280-wide output (the Llama-3-70B fused-qkv shard: 4096 x 1280) into exactly 32 x 8 = 256 workgroups — the 128 x 256 tile fills 160 of the 256 CUs
 template <int OUT>
 void launch_gemm_ringt(int tile, const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K, hipStream_t st,
                        int64_t a_slab_stride, int64_t a_k_per_slab) {
@@ -261,7 +263,12 @@ void launch_gemm_ringt(int tile, const int8_t* A, int64_t lda, const int8_t* B, 
         xs.magic = (uint32_t)(((1ull << 32) + (uint64_t)xs.tiles - 1) / (uint64_t)xs.tiles);
         xs.stride = a_slab_stride;
     }
-    if (tile == 0) {
+    if (tile == 2) {
+        const int tiles_m = (int)((M + 127) / 128), tiles_n = (int)((N + 159) / 160);
+        rot_plan(tiles_m < 8 ? tiles_m : 8, 160, &ct, &rd);
+        if (N * K < (6 << 20)) rd = 0;          // (weight streams that matter, as for the 128 x 128 ring tile)
+        gemm_s8_ringt<OUT, 128, 160, 4, 1><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd, xs);
+    } else if (tile == 0) {
         const int tiles_m = (int)((M + 63) / 64), tiles_n = (int)((N + 127) / 128);
         rot_plan(tiles_m < 8 ? tiles_m : 8, 128, &ct, &rd);
         gemm_s8_ringt<OUT, 64, 128, 3, 2><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st>>>(A, lda, B, ldb, epi, (int)M, (int)N, (int)K, tiles_m, tiles_n, ct, rd, xs);

@@ -52,7 +52,7 @@ int32_t check_launch(const char* what) {
     return PQ_OK;
 }
 
-enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY, V_RING64X128, V_RING64X64 };
+enum Variant { V_AUTO = 0, V_GENERIC, V_SP256_16, V_SP128_16, V_SP128X128, V_RING128, V_SKINNY, V_RING64X128, V_RING64X64, V_RING128X160 };
 
 Variant parse_variant(const char* e) {
     if (!e || !*e) return V_AUTO;
@@ -64,6 +64,7 @@ Variant parse_variant(const char* e) {
     if (!strcmp(e, "skinny")) return V_SKINNY;
     if (!strcmp(e, "ring64x128")) return V_RING64X128;
     if (!strcmp(e, "ring64x64")) return V_RING64X64;
+    if (!strcmp(e, "ring128x160")) return V_RING128X160;
     return V_AUTO;
 }
 
@@ -236,6 +237,7 @@ void run_gemm(Variant v, const int8_t* a, int64_t lda, const int8_t* b, int64_t 
     else if (v == V_SKINNY) pq::launch_gemm_skinny<OUT>(a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_RING64X128) pq::launch_gemm_ringt<OUT>(0, a, lda, b, ldb, epi, M, N, K, st);
     else if (v == V_RING64X64) pq::launch_gemm_ringt<OUT>(1, a, lda, b, ldb, epi, M, N, K, st);
+    else if (v == V_RING128X160) pq::launch_gemm_ringt<OUT>(2, a, lda, b, ldb, epi, M, N, K, st);
     else pq::launch_gemm_generic<OUT>(a, lda, b, ldb, epi, M, N, K, st);
 }
 
@@ -316,7 +318,7 @@ Variant kslabs_in_place(const int8_t* a, int64_t lda, int64_t slab_stride, int64
     if (options().no_kslabs || forced_variant() != V_AUTO || kps % 128 != 0 || K / 128 >= 65536 || (slab_stride & 15) != 0) return V_GENERIC;
     // (eligibility of the fast path is decided on the slab's own leading dimension and base; K itself is the whole K)
     const Variant v = pick_variant(a, lda, b, ldb, M, N, K);
-    return (v == V_RING128 || v == V_RING64X128 || v == V_RING64X64) ? v : V_GENERIC;
+    return (v == V_RING128 || v == V_RING64X128 || v == V_RING64X64 || v == V_RING128X160) ? v : V_GENERIC;
 }
 }  // namespace
 
@@ -569,7 +571,7 @@ size_t pq_qlinear_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     CallScope scope_;
     {   // (alignment of the operands is unknown here: assume the fast path, as pq_gemm_variant_name does)
         const Variant v = pick_variant(reinterpret_cast<const int8_t*>(16), K, reinterpret_cast<const int8_t*>(16), K, M, N, K);
-        if (v == V_RING64X128 || v == V_RING64X64) return 0;      // the mid-M tiles run single-pass
+        if (v == V_RING64X128 || v == V_RING64X64 || v == V_RING128X160) return 0;      // the mid-M tiles and the 128 x 160 tile run single-pass
     }
     if (const int f = fsk_plan(M, N, K)) return pq::fsk_workspace_bytes(M, N, f);
     int tm = 256;
@@ -706,6 +708,7 @@ const char* pq_kslabs_way_name(const int8_t* a, int64_t lda, int64_t slab_stride
         case V_RING128: return "in place: ring128";
         case V_RING64X128: return "in place: ring64x128";
         case V_RING64X64: return "in place: ring64x64";
+        case V_RING128X160: return "in place: ring128x160";
         default: return "layout pass";
     }
 }
@@ -748,7 +751,7 @@ int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, 
         auto go = [&](auto oc) {
             constexpr int OUT = decltype(oc)::value;
             if (v == V_RING128) pq::launch_gemm_ring128<OUT>(a, lda, b, ldb, epi, M, N, K, st, slab_stride, k_per_slab);
-            else pq::launch_gemm_ringt<OUT>(v == V_RING64X128 ? 0 : 1, a, lda, b, ldb, epi, M, N, K, st, slab_stride, k_per_slab);
+            else pq::launch_gemm_ringt<OUT>(v == V_RING64X128 ? 0 : (v == V_RING64X64 ? 1 : 2), a, lda, b, ldb, epi, M, N, K, st, slab_stride, k_per_slab);
         };
         switch (out_dtype) {
             case PQ_BF16: go(std::integral_constant<int, PQ_BF16>{}); break;
@@ -843,6 +846,7 @@ const char* pq_gemm_variant_name(int64_t M, int64_t N, int64_t K, int64_t lda, i
         case V_SKINNY: return "skinny_16x16x64";
         case V_RING64X128: return "ring64x128_16x16x64";
         case V_RING64X64: return "ring64x64_16x16x64";
+        case V_RING128X160: return "ring128x160_16x16x64";
         default: return "generic64";
     }
 }

@@ -89,7 +89,7 @@ def run(budget, seed):
       xs2 = (rng.random(M2).astype(np.float32) + 1e-3) * float(rng.choice([1e-3, 1.0, 50.0])); ws2 = rng.random(N2).astype(np.float32) * 0.02 + 1e-5
       bv = Q.from_f32(rng.standard_normal(N2).astype(np.float32), code) if rng.random() < 0.5 else None
       want = Q.epilogue(acc, xs2, ws2, bv, code)
-      for v in ("", "generic", "ring128", "sp256_16"):
+      for v in ("", "generic", "ring128", "sp256_16", "ring128x160"):
           _pqlib.set_option("PQ_FORCE_VARIANT", v)
           got = pq.qlinear_s8(torch.from_numpy(a).cuda(), torch.from_numpy(xs2).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws2).cuda(),
                               to_gpu(bv, code) if bv is not None else None, TD[code])

@@ -93,7 +93,7 @@ def _every_element(y, xq, wq, xs, ws, bias):
 
 
 # y of more than 2^31 elements, both ways round: tall (M large) and wide (N large); K small so the int matmul of the sampled rows is cheap
-@pytest.mark.parametrize("variant", ["auto", "sp256_16", "sp128_16", "ring128", "ring64x128", "ring64x64", "generic"])
+@pytest.mark.parametrize("variant", ["auto", "sp256_16", "sp128_16", "ring128", "ring64x128", "ring64x64", "ring128x160", "generic"])
 @pytest.mark.parametrize("tall", [True, False])
 def test_gemm_outputs_past_2g_elements(pq, pq_opt, variant, tall):
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)

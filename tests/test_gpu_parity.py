@@ -37,7 +37,7 @@ def test_golden_quantize(pq, golden):
     same_f(pq.dequantize(qc), g["x_coldeq"], g["code"], "x_coldeq")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "ring128x160"])
 def test_golden_gemm_and_qlinear(pq, golden, variant, pq_opt):
     g = golden
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -70,7 +70,7 @@ SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (100, 200, 300), (255, 257, 128), 
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "ring128x160"])
 def test_int_gemm_exact_full_range(pq, M, N, K, variant, pq_opt):
     """Full-range int8 operands (incl. -128) and an asymmetric B: exact int32 vs int64 matmul."""
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
@@ -82,7 +82,7 @@ def test_int_gemm_exact_full_range(pq, M, N, K, variant, pq_opt):
     same(got, want, f"acc {M}x{N}x{K} {variant}")
 
 
-@pytest.mark.parametrize("variant", ["sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "generic"])
+@pytest.mark.parametrize("variant", ["sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "ring128x160", "generic"])
 def test_gemm_identity_asymmetric(pq, variant, pq_opt):
     """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
     pq_opt("PQ_FORCE_VARIANT", variant)
@@ -168,7 +168,7 @@ def test_quant_strided_and_unaligned(pq):
 
 @pytest.mark.parametrize("M,N,K,code,bias", [(300, 520, 640, 0, True), (256, 512, 1024, 1, True), (77, 130, 384, 2, False),
                                               (512, 1024, 512, 0, False)])
-@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "ring128x160"])
 def test_qlinear_vs_oracle(pq, M, N, K, code, bias, variant, pq_opt):
     pq_opt("PQ_FORCE_VARIANT", "" if variant == "auto" else variant)
     rng = np.random.default_rng(M + N + K + code)

@@ -11,7 +11,7 @@ L.pq_qlinear_s8.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i64, i64
 L.pq_qlinear_workspace_bytes.restype = sz; L.pq_qlinear_workspace_bytes.argtypes = [i64, i64, i64]
 L.pq_gemm_variant_name.restype = ctypes.c_char_p; L.pq_gemm_variant_name.argtypes = [i64, i64, i64, i64, i64]
 L.pq_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
-VARS = ["", "sp256_16", "sp128_16", "ring128", "ring64x128", "ring64x64", "skinny"]
+VARS = ["", "sp256_16", "sp128_16", "ring128", "ring64x128", "ring64x64", "ring128x160", "skinny"]
 quick = "--quick" in sys.argv
 Ms = [48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192]
 if "--small" in sys.argv:            # the decode-like end: the weight-streaming kernel against the 64-row ring tiles

@@ -6,7 +6,7 @@ import numpy as np, torch
 import protoquant_amd as pq
 from protoquant_amd import _lib as _pqlib  # noqa: E402
 
-VARIANTS = ["", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "skinny"]
+VARIANTS = ["", "sp256_16", "sp128_16", "sp128x128", "ring128", "ring64x128", "ring64x64", "ring128x160", "skinny"]
 DT = [torch.bfloat16, torch.float16, torch.float32]
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 budget = float(os.environ.get("FUZZ_SECONDS", "120"))
