@@ -144,7 +144,7 @@ def test_bench_tp_watchdog_keeps_the_native_legs_that_finished():
 def test_bench_tp_supervisor_keeps_the_safe_line_when_the_worker_dies():
     """tp runs over more than one rank put every rank's real work into a CHILD of a GPU-free supervisor process (bench.py: supervise): a fault inside a native
     collective — a segfault, a GPU memory fault — cannot be caught in the process it kills, so the worker reports every line it could print so far through a pipe
-    and the supervisor prints the last one.  Here at one rank (--supervise), the worker killing itself with SIGSEGV when it reaches the native exchange: the line of
+    and the supervisor prints the last one.  Here at one rank (PQ_BENCH_TEST_HOOKS=supervise,native-crash), the worker killing itself with SIGSEGV when it reaches the native exchange: the line of
     the verified torch.distributed legs comes out, marked "native_exchange": "crashed", and the exit status is 0."""
     r, lines = _bench_tp([], "29568", hooks="supervise,native-crash")
     assert r.returncode == 0, r.stderr[-3000:]
