@@ -323,7 +323,7 @@ def main():
     gemm_ops = 2.0 * M * N * K
     variant = lib.pq_gemm_variant_name(M, N, K, K, K).decode()
     kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
-             "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
+             "skinny": "gemm_s8_skinny (K3+K4)"}.get("" if variant.startswith(("ring128x160", "ring64")) else variant.split("_")[0].split("x")[0], variant)
     if wbytes > 0:
         kname += " split-K + splitk_reduce_epilogue"
 

@@ -327,7 +327,7 @@ def run_tp(args, world, rank, dev, dist, cpu_fn=None):
         h = done[head] if head else done[timed[0]]          # (no verified leg: the line carries value 0 and verified = false)
         variant = lib.pq_gemm_variant_name(M, n_local, K, K, K).decode()
         kname = {"sp256": "gemm_s8_sp256 (K3+K4)", "sp128": "gemm_s8_sp256<128x256, loader/consumer> (K3+K4)", "ring128": "gemm_s8_ring128<loader/consumer> (K3+K4)",
-                 "skinny": "gemm_s8_skinny (K3+K4)"}.get(variant.split("_")[0].split("x")[0], variant)
+                 "skinny": "gemm_s8_skinny (K3+K4)"}.get("" if variant.startswith(("ring128x160", "ring64")) else variant.split("_")[0].split("x")[0], variant)
         if lib.pq_qlinear_workspace_bytes(M, n_local, K) > 0:
             kname += " split-K + splitk_reduce_epilogue"
         gemm_ops, gemm_bytes, k1_bytes = 2.0 * M * n_local * K, M * K + n_local * K + 2 * M * n_local + 4 * (M + n_local), 3 * M * K + 4 * M

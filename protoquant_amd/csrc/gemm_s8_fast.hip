@@ -1019,11 +1019,22 @@ bool fsk_kslabs_ok(int64_t K, int64_t k_per_slab, int kslices) {
     const int64_t nslabs = K / k_per_slab;
     return nslabs % kslices == 0 || kslices % nslabs == 0;
 }
+// the tickets and ready counts / flags of a launch are zeroed by a KERNEL of our own, not by hipMemsetAsync (round 6): a hipGraph that holds [memset node, fused split-K
+// kernel] hung on its next replay as soon as ANY other graph without such a node had been captured after it (round-5 and round-6 libraries alike, ROCm 7.0 / torch 2.10:
+// profiles/r06_hipgraph_memset_hang.txt) — the kernel's last arriver polls a `ready` count that the memset node did not (or not in order) reset.  A kernel node has no such problem.
+__global__ void fsk_zero_counters(uint32_t* p, int n) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
 template <int OUT>
 bool launch_gemm_fsk(const int8_t* A, int64_t lda, const int8_t* B, int64_t ldb, const EpiArgs& epi, int64_t M, int64_t N, int64_t K,
                      int kslices, void* workspace, hipStream_t st, int64_t a_slab_stride, int64_t a_k_per_slab) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    if (hipMemsetAsync(workspace, 0, fsk_counter_bytes(tiles_m * tiles_n, kslices), st) != hipSuccess) return false;   // tickets and ready counts / flags
+    {
+        const int nwords = (int)(fsk_counter_bytes(tiles_m * tiles_n, kslices) / 4);
+        fsk_zero_counters<<<dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st>>>(static_cast<uint32_t*>(workspace), nwords);   // tickets and ready counts / flags
+        if (hipGetLastError() != hipSuccess) return false;
+    }
     const dim3 grid((unsigned)(tiles_m * tiles_n * kslices)), block(512);
     unsigned long long* const ws = static_cast<unsigned long long*>(workspace);
     if (a_k_per_slab > 0 && a_k_per_slab < K) {      // stacked activation codes walked in place (the caller checked fsk_kslabs_ok)

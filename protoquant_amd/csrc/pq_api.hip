@@ -79,7 +79,7 @@ thread_local const pq::Options* tl_opt = nullptr;      // the snapshot pinned by
 thread_local int tl_depth = 0;
 
 // every behaviour switch, by name: the ONE place both the environment pass (once) and pq_set_option go through
-const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FSK_COOP", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_NO_KSLABS", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
+const char* const kOptionNames[] = {"PQ_FORCE_VARIANT", "PQ_NO_TAILSPLIT", "PQ_NO_SPLITK", "PQ_FORCE_SPLITK", "PQ_FSK", "PQ_FSK_SYMMETRIC", "PQ_FSK_FENCED", "PQ_FSK_COOP", "PQ_FAKE_CUS", "PQ_NO_MIDM", "PQ_NO_KSLABS", "PQ_NO_RING160", "PQ_MIDM_CT", "PQ_RMS_WAVE_MAX", "PQ_SILU_TPR", "PQ_SP128_LC",
                                     "PQ_SP256_P3", "PQ_SP256_ASM", "PQ_SP256_PERSIST", "PQ_RING_LC", "PQ_RING_ROT", "PQ_K1_LDS", "PQ_EPI_ANY_ALIGN", "PQ_K2_BLOCKS_A", "PQ_K2_BLOCKS_E", "PQ_K1_RPW", "PQ_K1_ST16", "PQ_SKINNY_RB", "PQ_SKINNY_STAGE", "PQ_SKINNY_KS"};
 bool apply_option(pq::Options& o, const char* name, const char* value) {
     const bool set = value && *value;
@@ -95,6 +95,7 @@ bool apply_option(pq::Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "PQ_FAKE_CUS")) o.fake_cus = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_NO_MIDM")) o.no_midm = set;
     else if (!strcmp(name, "PQ_NO_KSLABS")) o.no_kslabs = set;
+    else if (!strcmp(name, "PQ_NO_RING160")) o.no_ring160 = set;
     else if (!strcmp(name, "PQ_MIDM_CT")) o.midm_ct = iv > 0 ? iv : 0;
     else if (!strcmp(name, "PQ_RMS_WAVE_MAX")) o.rms_wave_max = !set || iv < 0 ? 256 : (iv > 512 ? 512 : iv);
     else if (!strcmp(name, "PQ_SILU_TPR")) o.silu_tpr = set && !strcmp(value, "256") ? 256 : 0;
@@ -222,7 +223,15 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
         }
         return V_RING128;
     }
-    if (t256 <= cus * 5 / 8 && t128 > t256 && t128 <= cus) return V_SP128_16;
+    if (t256 <= cus * 5 / 8 && t128 > t256 && t128 <= cus) {
+        // round 6: where the 128 x 256 tiles fill at most two thirds of the chip but 128 x 160 tiles make (almost) exactly one round of it — the Llama-3-70B fused-qkv shard
+        // 4096 x 1280: 160 against 256 workgroups — the 128 x 160 ring tile (gemm_s8_ringt<128, 160>).  Measured over that class, weights from HBM, two boxes
+        // (profiles/r06_dispatch_audit_tile160.txt, r06_ab_tile160.txt): 8 - 14 % ahead on 11 of 12 shapes with K >= 4096 (4096 x 1280 x 4096: +-3 %); everywhere outside the
+        // class it loses 8 - 90 %.  PQ_NO_RING160=1 restores the round-5 choice.
+        const int64_t t160 = ((M + 127) / 128) * ((N + 159) / 160);
+        if (!options().no_ring160 && K >= 4096 && t160 <= cus && t160 * 10 >= cus * 9 && t128 * 3 <= cus * 2) return V_RING128X160;
+        return V_SP128_16;
+    }
     return V_SP256_16;
 }
 
@@ -371,7 +380,7 @@ int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t col
         case PQ_FP16: e = pq::quant_colwise_dispatch<PQ_FP16>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
         default: e = pq::quant_colwise_dispatch<PQ_F32>(x, rows, cols, ld_x, q, ld_q, scale, st); break;
     }
-    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_quant_colwise: hipMemsetAsync of the amax scratch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(PQ_ERR_LAUNCH, "pq_quant_colwise: initialising the amax scratch: %s", hipGetErrorString(e));
     return check_launch("pq_quant_colwise");
 }
 
@@ -601,7 +610,7 @@ static int32_t qlinear_core(const char* what, const int8_t* a, int64_t lda, cons
             case PQ_FP16: launched = pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
             default: launched = pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st); break;
         }
-        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "%s: the split-K workspace could not be initialised (hipMemsetAsync failed)", what); }
+        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "%s: the split-K workspace could not be initialised (the zeroing launch failed)", what); }
         return check_launch(what);
     }
     int tm = 256;
@@ -739,7 +748,7 @@ int32_t pq_qlinear_s8_kslabs(const int8_t* a, int64_t lda, int64_t slab_stride, 
             case PQ_FP16: launched = pq::launch_gemm_fsk<PQ_FP16>(a, lda, b, ldb, epi, M, N, K, f, workspace, st, slab_stride, k_per_slab); break;
             default: launched = pq::launch_gemm_fsk<PQ_F32>(a, lda, b, ldb, epi, M, N, K, f, workspace, st, slab_stride, k_per_slab); break;
         }
-        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8_kslabs: the split-K workspace could not be initialised (hipMemsetAsync failed)"); }
+        if (!launched) { (void)hipGetLastError(); return fail(PQ_ERR_WORKSPACE, "pq_qlinear_s8_kslabs: the split-K workspace could not be initialised (the zeroing launch failed)"); }
         return check_launch("pq_qlinear_s8_kslabs");
     }
     if (const Variant v = kslabs_in_place(a, lda, slab_stride, k_per_slab, b, ldb, M, N, K); v != V_GENERIC) {

@@ -30,6 +30,7 @@ struct Options {
     bool fsk_symmetric = false;      // PQ_FSK_SYMMETRIC=1: the symmetric exchange for 2 / 4 slices (waits for partner workgroups: see pq_hip.h); default: the ticket form
     int midm_ct = 0;                 // PQ_MIDM_CT: K-tiles per rotation chunk of the mid-M ring tiles (0 = by rule, 1 = no rotation)
     bool no_kslabs = false;          // PQ_NO_KSLABS=1: pq_qlinear_s8_kslabs always takes the layout pass (never walks the slabs in place)
+    bool no_ring160 = false;        // PQ_NO_RING160=1: never plan the 128 x 160 ring tile (round 6)
     bool no_midm = false;            // PQ_NO_MIDM=1: no 64-row ring tiles for 64 < M <= 512 (the round-3 dispatch)
     bool fsk_coop = false;           // PQ_FSK_COOP=1: launch the symmetric fused split-K kernels COOPERATIVELY (co-residency guaranteed by the runtime, ticket form on error).
                                      // Off by default: measured +21-24 us per launch on ROCm 7.2 / gfx950, against 2-5 us the symmetric exchange saves (profiles/r05_ab_fsk_coop.txt)

@@ -503,6 +503,10 @@ void quant_rowwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t l
     }
 }
 
+__global__ void fill_words(uint32_t* p, uint32_t v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
 template <int DT>
 hipError_t quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int64_t ldx, int8_t* q, int64_t ldq,
                                   float* scale, hipStream_t st) {
@@ -527,7 +531,9 @@ hipError_t quant_colwise_dispatch(const void* x, int64_t rows, int64_t cols, int
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
     const int64_t ldb = ldx * Elem<DT>::kBytes;
     uint32_t* words = reinterpret_cast<uint32_t*>(scale);
-    const hipError_t me = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(words), (int)kAmaxTag, (size_t)cols, st);   // "amax 0" (the atomicMax identity)
+    // "amax 0" (the atomicMax identity) by a kernel of our own, not a memset node (round 6: gemm_s8_fast.hip, fsk_zero_counters — memset nodes in a hipGraph misbehaved)
+    fill_words<<<dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st>>>(words, kAmaxTag, cols);
+    const hipError_t me = hipGetLastError();
     if (me != hipSuccess) return me;                                                      // never launch on an un-initialised scratch
     if (rows > 0) {
         if (vec_ok) {

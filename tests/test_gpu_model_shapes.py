@@ -93,7 +93,7 @@ def test_llama8b_prefill_shapes(pq, N, K, variant, bias):
     (1024, 28672, "ring128", False),          # down shard (column-sharded: full K)
     (16032, 8192, "sp256_16x16x64", False),   # lm_head shard: 128256 / 8 = 16032 = 62.6 tile columns (ragged last tile)
     (128, 8192, "", False),                   # k / v shard (8 KV heads x 128 / 8 GPUs)
-    (1280, 8192, "sp128x256", True),          # FUSED q+k+v shard, what bench.py --workload llama70b-shard runs: (8192 + 2 x 1024) / 8
+    (1280, 8192, "ring128x160", True),        # FUSED q+k+v shard, what bench.py --workload llama70b-shard runs: (8192 + 2 x 1024) / 8 — round 6: 32 x 8 = 256 tiles of 128 x 160
     (7168, 8192, "sp256_16x16x64", False),    # FUSED gate+up shard: 2 x 28672 / 8 (28 tile columns x 16 = 448 tiles: 1.75 rounds)
 ])
 def test_llama70b_shard_shapes(pq, N, K, variant, bias, pq_opt):

@@ -95,6 +95,11 @@ def test_planner_follows_the_devices_cu_count(L):
                     (512, 4096, 4096): "ring64x128_16x16x64", (4096, 14336, 4096): "sp256_16x16x64 + sp128 tail (N)"}
     L.pq_set_option(b"PQ_FAKE_CUS", b"")
     assert {s: name(*s) for s in full} == full            # (no GPU here: the query falls back to 256; on the GPU box the real count — 256 — gives the same)
+    # round 6: the 128 x 160 ring tile where 128 x 256 tiles fill <= 2/3 of the chip and 128 x 160 tiles make one round of it (the 70B fused-qkv shard); PQ_NO_RING160 restores round 5
+    assert name(4096, 1280, 8192) == "ring128x160_16x16x64" and name(2048, 2560, 4096) == "ring128x160_16x16x64" and name(4096, 1280, 2048) == "sp128x256_16x16x64"
+    L.pq_set_option(b"PQ_NO_RING160", b"1")
+    assert name(4096, 1280, 8192) == "sp128x256_16x16x64"
+    L.pq_set_option(b"PQ_NO_RING160", b"")
     L.pq_set_option(b"PQ_FAKE_CUS", b"128")
     assert name(4096, 1024, 8192) == "sp128x256_16x16x64" and name(4096, 2048, 4096) == "sp256_16x16x64" and name(512, 4096, 4096) == "ring128_16x16x64"
     assert name(2048, 11008, 4096) == "sp256_16x16x64"    # 344 tiles on 128 CUs: 2.7 rounds, no poorly filled tail worth a second launch
