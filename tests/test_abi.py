@@ -82,3 +82,13 @@ def test_product_has_no_cpu_fallback_and_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_no_memset_node_left_in_the_product():
+    """round 6: a hipMemsetAsync node inside a captured graph hung the fused split-K on replay once another graph had been captured (profiles/r06_hipgraph_memset_hang.txt):
+    the library initialises its counters and scratch with kernels of its own"""
+    for f in os.listdir(os.path.join(ROOT, "protoquant_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            for ln in open(os.path.join(ROOT, "protoquant_amd", "csrc", f)):
+                code = ln.split("//")[0]
+                assert "hipMemset" not in code, (f, ln.strip()[:120])

@@ -14,11 +14,3 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_fused_splitk_graph_survives_later_captures():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "two_graphs_worker.py")], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "OK two graphs" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
-
-
-def test_no_memset_node_left_in_the_product():
-    for f in os.listdir(os.path.join(ROOT, "protoquant_amd", "csrc")):
-        if f.endswith((".hip", ".h")):
-            for ln in open(os.path.join(ROOT, "protoquant_amd", "csrc", f)):
-                code = ln.split("//")[0]
-                assert "hipMemset" not in code, (f, ln.strip()[:120])
