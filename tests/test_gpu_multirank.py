@@ -91,13 +91,17 @@ def test_bench_tp_step_is_one_graph_world1():
     assert line["roofline"]["frac"] > 0.3 and line["timings_consistent"] is True and line["cpu_baseline"] is None
 
 
-def _bench_tp(extra, port, hooks="", cpu_baseline=False, env_extra=None):
+def _bench_tp(extra, port, hooks="", cpu_baseline=False, env_extra=None, _retried=False):
     """bench.py --mode tp at world 1; `hooks` = PQ_BENCH_TEST_HOOKS (the test hooks live in the environment, not on bench.py's command line: round 6)"""
     env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", PQ_BENCH_TEST_HOOKS=hooks, **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "tp", "--steps", "6", "--warmup", "2", "--repeats", "3", "--warmup-seconds", "0.3",
                         *([] if cpu_baseline else ["--no-cpu-baseline"]), "--no-dp-leg", *extra], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "bad_variant_access" in r.stderr and not _retried:
+        # torch.distributed's own start-up died once in ~40 runs of round 6 with `std::bad_variant_access` before the communicator existed (0 of 160 in tools/init_stress.py):
+        # not this repository's code, so one retry keeps the suite from failing on it — a second failure is reported
+        return _bench_tp(extra, port, hooks, cpu_baseline, env_extra, _retried=True)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, lines
 
