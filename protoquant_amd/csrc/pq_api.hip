@@ -229,7 +229,8 @@ Variant pick_variant(const int8_t* a, int64_t lda, const int8_t* b, int64_t ldb,
         // (profiles/r06_dispatch_audit_tile160.txt, r06_ab_tile160.txt): 8 - 14 % ahead on 11 of 12 shapes with K >= 4096 (4096 x 1280 x 4096: +-3 %); everywhere outside the
         // class it loses 8 - 90 %.  PQ_NO_RING160=1 restores the round-5 choice.
         const int64_t t160 = ((M + 127) / 128) * ((N + 159) / 160);
-        if (!options().no_ring160 && K >= 4096 && t160 <= cus && t160 * 10 >= cus * 9 && t128 * 3 <= cus * 2) return V_RING128X160;
+        if (!options().no_ring160 && options().force_splitk <= 1 && options().fsk <= 1 &&      // (a forced slice count — experiments, tests — means the split-K forms, as for the mid-M tiles)
+            K >= 4096 && t160 <= cus && t160 * 10 >= cus * 9 && t128 * 3 <= cus * 2) return V_RING128X160;
         return V_SP128_16;
     }
     return V_SP256_16;

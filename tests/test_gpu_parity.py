@@ -297,6 +297,33 @@ def test_fused_splitk_matches(pq, M, N, S, NT, code, bias, pq_opt):
     assert torch.equal(out.view(torch.uint8), y_def.view(torch.uint8)), "cooperative fused split-K under capture"
 
 
+@pytest.mark.parametrize("M,N,S,NT", [(300, 300, 3, 17), (520, 260, 3, 64), (260, 300, 5, 27), (4096, 1280, 3, 64), (300, 520, 7, 36)])
+def test_fused_splitk_with_uneven_slices(pq, pq_opt, M, N, S, NT):
+    """round 6: the ticket form deals the K-tiles as evenly as they go — NT K-tiles over S slices, the first NT % S slices one more (3 slices of 64: 22 / 21 / 21; 5 of 27: 6 / 6 / 5 / 5 / 5,
+    the minimum of five per slice) — where rounds 3-5 wanted K % (128 S) == 0.  Bit-identical to the single-pass dispatch and (small shapes) to the oracle, repeated on one workspace."""
+    from protoquant_amd import _lib
+    K = NT * 128
+    assert K % (128 * S) != 0
+    rng = np.random.default_rng(M + N + K + S)
+    a = rng.integers(-128, 128, (M, K), dtype=np.int8); b = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    xs = rng.random(M).astype(np.float32) * 0.1; ws = rng.random(N).astype(np.float32) * 0.01
+    bv = Q.from_f32(rng.standard_normal(N).astype(np.float32), 0)
+    args = (torch.from_numpy(a).cuda(), torch.from_numpy(xs).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(ws).cuda(), to_gpu(bv, 0), torch.bfloat16)
+    pq_opt("PQ_FSK", "0")
+    y_def = pq.qlinear_s8(*args)
+    if M * N <= 1 << 18:
+        acc = (a.astype(np.float64) @ b.astype(np.float64).T).astype(np.int32)
+        same(y_def, Q.epilogue(acc, xs, ws, bv, 0), "default dispatch y")
+    pq_opt("PQ_FSK", str(S))
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert _lib.lib().pq_qlinear_workspace_bytes(M, N, K) == ((tiles * 4 * (4 if S == 4 else 2) + 255) // 256) * 256 + tiles * (S - 1) * 256 * 256 * 4
+    for rep in range(4):
+        y = pq.qlinear_s8(*args)
+        assert torch.equal(y.view(torch.uint8), y_def.view(torch.uint8)), f"uneven fused split-K y (rep {rep})"
+    pq_opt("PQ_FSK_SYMMETRIC", "1")                      # the symmetric forms keep equal slices: an uneven K is refused by that plan (the planner's other choices run): same bits
+    assert torch.equal(pq.qlinear_s8(*args).view(torch.uint8), y_def.view(torch.uint8))
+
+
 @pytest.mark.parametrize("cus", [32, 64, 128, 256])
 def test_plans_made_for_fewer_cus_stay_bit_exact(pq, pq_opt, cus):
     """PQ_FAKE_CUS (a partitioned / CU-masked device as the planner would see it, with its XCD count: one per 32 CUs in the tile remaps): every plan the smaller
