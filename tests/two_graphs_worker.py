@@ -43,9 +43,9 @@ q_out = torch.empty((M, K), dtype=torch.int8, device=dev)
 g_c = capture(lambda: pq.quantize(x16))              # a third graph: K1 alone
 _lib.set_option("PQ_FSK", "")
 for it in range(30):
+    if it % 3 == 0:
+        y_fsk.zero_(); y_b.zero_()
     for g in (g_fsk, g_b, g_c):
-        if it % 3 == 0:
-            y_fsk.zero_(); y_b.zero_()
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(y_fsk.view(torch.int16), ref.view(torch.int16)) and torch.equal(y_b.view(torch.int16), ref.view(torch.int16)), it
