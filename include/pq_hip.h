@@ -48,7 +48,8 @@ int32_t pq_version(void);
 /* Message of the last failing call on the calling thread ("" if none). Valid until the next call. */
 const char* pq_last_error(void);
 /* Behaviour switches for tests and experiments: PQ_FORCE_VARIANT (generic | sp256_16 | sp128_16 | sp128x128 | ring128 |
- * ring64x128 | ring64x64 | skinny | "" = auto), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
+ * ring64x128 | ring64x64 | ring128x160 | skinny | "" = auto), PQ_NO_RING160 (1 = never plan the 128 x 160 ring tile: the round-5 dispatch), PQ_NO_KSLABS (1 = stacked codes always take
+ * the layout pass), PQ_NO_TAILSPLIT, PQ_NO_SPLITK, PQ_FORCE_SPLITK (slice count: experiments), PQ_FSK (0 = no fused
  * split-K, S = S slices), PQ_FSK_SYMMETRIC and PQ_FSK_FENCED (see pq_qlinear_s8), PQ_NO_MIDM (no 64-row ring tiles), PQ_RING_ROT (0 = no K rotation), PQ_FAKE_CUS (plan as if the device had n CUs),
  * PQ_SKINNY_RB ("" = off / auto), PQ_EPI_ANY_ALIGN (0 = the staged epilogue only for 16-byte aligned output rows; default: any element-aligned row),
  * PQ_K2_BLOCKS_A / PQ_K2_BLOCKS_E (workgroup-count targets of K2's two passes).  The environment variables of the same names are read ONCE, at the first call into the
