@@ -1,4 +1,5 @@
 #!/bin/bash
+# Dev tool (GPU box): the whole -m gpu suite with the 30 slowest tests, then smoke().  usage: bash tools/gpu_suite.sh <outdir under gpurun_out>
 set -u
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$1
