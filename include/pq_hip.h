@@ -68,7 +68,7 @@ int32_t pq_quant_rowwise(const void* x, int32_t dtype, int64_t rows, int64_t col
 
 /* K2 — per-channel quantisation of a row-major matrix along its strided axis (amax over rows):
  * replaces quantize(W) for a [K, N]-stored weight.  scale[cols] f32.  Three stream-ordered graph nodes
- * (a 32-bit memset, the amax pass, the encode pass); `scale` doubles as the amax scratch — no workspace.   QSPEC Q1-Q6. */
+ * (a fill kernel, the amax pass, the encode pass: three kernel nodes under capture); `scale` doubles as the amax scratch — no workspace.   QSPEC Q1-Q6. */
 int32_t pq_quant_colwise(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld_x,
                          int8_t* q, int64_t ld_q, float* scale, void* stream);
 
