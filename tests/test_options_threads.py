@@ -110,3 +110,39 @@ def test_planner_follows_the_devices_cu_count(L):
     L.pq_set_option(b"PQ_FAKE_CUS", b"32")
     assert name(1024, 1024, 4096) == "sp128x256_16x16x64" and name(4096, 1280, 8192) == "sp256_16x16x64 + sp128 tail (N)"
     L.pq_set_option(b"PQ_FAKE_CUS", b"")
+
+
+def test_kslabs_workspace_queries_are_consistent_over_random_shapes():
+    """round 6, no GPU (the planner falls back to 256 CUs): for any shape and slab count the short query (always enough) is >= the exact one, the exact one is what the named way
+    needs, and a workspace of the exact size never names a way that needs more."""
+    import ctypes
+    import random
+    from protoquant_amd import _lib
+    L = _lib.lib()
+    rnd = random.Random(6)
+    ways = set()
+    for _ in range(3000):
+        G = rnd.choice([1, 2, 3, 4, 8])
+        tps = rnd.choice([1, 2, 3, 4, 7, 8, 14, 28, 43, 56])
+        kps = tps * 128 if rnd.random() < 0.9 else tps * 128 + rnd.choice([16, 64, 100])
+        K = G * kps
+        M = rnd.choice([1, 16, 64, 65, 130, 300, 512, 1024, 2048, 4096, 8192])
+        N = rnd.choice([96, 128, 130, 257, 512, 1024, 1280, 2560, 3584, 4096, 7168, 14336])
+        lda = kps + rnd.choice([0, 0, 16, 128, 3])
+        stride = M * lda + rnd.choice([0, 0, 256, 48, 5])
+        a = ctypes.c_void_p(4096 + rnd.choice([0, 0, 0, 8]))
+        b = ctypes.c_void_p(8192)
+        short = L.pq_qlinear_kslabs_workspace_bytes(M, N, K, kps)
+        exact = L.pq_qlinear_kslabs_workspace_bytes_for(a, lda, stride, kps, b, K, M, N, K)
+        way = L.pq_kslabs_way_name(a, lda, stride, kps, b, K, M, N, K, exact).decode()
+        ways.add(way.split(" x")[0])
+        assert short >= exact, (M, N, K, G, lda, stride, short, exact, way)
+        if way.startswith("in place: ring"):
+            assert exact == 0, (way, exact)
+        elif way == "layout pass":
+            assert exact >= M * K, (way, exact, M, K)
+        elif "fused split-K" in way:
+            assert 0 < exact < short and G > 1 and kps % 128 == 0 and kps >= 512 and (lda % 16 == 0) and (stride % 16 == 0) and a.value % 16 == 0, (way, M, N, K, G, lda, stride)
+            # without a workspace the same operands take another way — never an error
+            assert "fused split-K" not in L.pq_kslabs_way_name(a, lda, stride, kps, b, K, M, N, K, 0).decode()
+    assert {"in place: ring128", "layout pass", "in place: fused split-K", "one slab: pq_qlinear_s8"} <= ways, ways
