@@ -24,5 +24,27 @@ for n in (192, 1 << 10, 1 << 20):
         ga.replay(); gb.replay(); torch.cuda.synchronize()
         bad += int((out != 1.0).sum().item())
     print(f"n={n}: torch zero_() node under capture, later graph captured: wrong elements over 50 replays = {bad}", flush=True)
-# which node type does torch's zero_ become?  (kernel-trace will tell; here just report)
+# the same with a RAW hipMemsetAsync node (what the library used to issue for its tile tickets) instead of torch's zero_()
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+hip.hipMemsetAsync.restype = ctypes.c_int
+for n in (192, 1 << 10, 1 << 20):
+    t = torch.empty(n, device=dev); out = torch.empty(n, device=dev); u = torch.randn(1 << 20, device=dev); v = torch.empty_like(u)
+    def fa():
+        assert hip.hipMemsetAsync(t.data_ptr(), 0, 4 * n, torch.cuda.current_stream().cuda_stream) == 0
+        torch.add(t, 1.0, out=out)
+    def fb(): torch.mul(u, 2.0, out=v)
+    for later in (False, True):
+        ga = capture(fa)
+        gb = capture(fb) if later else None
+        bad = 0
+        for it in range(50):
+            t.fill_(5.0); out.fill_(-1.0)
+            ga.replay()
+            if gb is not None:
+                gb.replay()
+            torch.cuda.synchronize()
+            bad += int((out != 1.0).sum().item())
+        print(f"n={n}: RAW hipMemsetAsync node under capture, {'a later graph captured' if later else 'NO later graph'}: wrong elements over 50 replays = {bad} of {50 * n}", flush=True)
 print("done")
